@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- scored windows/s of the seq+struct sliding-window scan (w=12) on MI355X.
+
+Workload (BASELINE.json configs[2], "C3"): 100k synthetic RNA records x 3 kb,
+uint8 letter codes + averaged-structure profile (7 x float32 per position),
+sequence PFM and structure PFM of width 12, all-scores mode (one float32 sequence
+score + one float64 structure score per window).  A "step" is ONE pass of the hot
+path over the whole batch, inputs already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: records are independent, so every rank scans its own
+100k-record shard (weak scaling), no data-path collective; only the timing
+barrier and a MAX over ranks use RCCL.
+
+Prints ONE JSON line (rank 0).  ``roofline`` is computed from the ALGORITHMIC
+bytes (29 B read per position + 12 B written per window)
+and the average kernel duration measured with HIP events on the launch stream.
+``cpu_baseline`` times the CPU oracle (oracle/pfm_oracle.c, OpenMP) on a bounded
+sample of the same records on this box's host cores, and the same sample is
+used as a parity check of the GPU scores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_pssms(width):
+    """Seeded PFMs -> log-odds operands: rows ~ Dirichlet(0.5), pseudocount 0.01,
+    uniform background (finite variant)."""
+    from rnascan_amd import pssm, pack
+    from collections import OrderedDict
+    rs = np.random.RandomState(11)
+    seq_counts = rs.dirichlet(np.full(4, 0.5), size=width)
+    rs = np.random.RandomState(13)
+    st_counts = rs.dirichlet(np.full(7, 0.5), size=width)
+    seq = OrderedDict((l, seq_counts[:, k]) for k, l in enumerate("ACGU"))
+    st = OrderedDict((l, st_counts[:, k]) for k, l in enumerate(pack.STRUCT_COLUMNS))
+    seq_p = pssm.PSSM("ACGU", pssm.log_odds(pssm.normalize(seq, 0.01), None))
+    st_p = pssm.PSSM(pack.STRUCT_COLUMNS, pssm.log_odds(pssm.normalize(st, 0.01), None))
+    return seq_p.letter_table("ACGU"), st_p.matrix(pack.STRUCT_COLUMNS)
+
+
+def make_stream(torch, dev, records, length, seed):
+    """Synthetic records generated ON DEVICE: letters iid uniform over ACGU, profile
+    rows ~ Dirichlet(0.3) stored float32; every record followed by one separator."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    stride = length + 1
+    n_pos = records * stride
+    codes = torch.randint(0, 4, (records, stride), dtype=torch.uint8, device=dev, generator=g)
+    codes[:, length] = 7
+    profile = torch.empty((n_pos, 7), dtype=torch.float32, device=dev)
+    chunk = 1 << 24
+    for lo in range(0, n_pos, chunk):
+        hi = min(n_pos, lo + chunk)
+        x = torch._standard_gamma(torch.full((hi - lo, 7), 0.3, dtype=torch.float32, device=dev), generator=g)
+        x.clamp_(min=1e-30)
+        profile[lo:hi] = x / x.sum(dim=1, keepdim=True)
+        del x
+    profile.view(records, stride, 7)[:, length, :] = 0
+    return codes.view(-1), profile, n_pos
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--records", type=int, default=100000, help="records per GPU")
+    ap.add_argument("--length", type=int, default=3000)
+    ap.add_argument("--width", type=int, default=12)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from rnascan_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libpfmscan has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = _lib.Context(local_rank)
+    table, spssm = make_pssms(args.width)
+    motif = ctx.motif(table, spssm)
+    codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank)
+    out_seq = torch.empty(n_pos, dtype=torch.float32, device=dev)
+    out_st = torch.empty(n_pos, dtype=torch.float64, device=dev)
+    windows = args.records * (args.length - args.width + 1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos,
+                     out_seq.data_ptr(), out_st.data_ptr(), stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps          # HIP events on the launch stream
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    result = None
+    if rank == 0:
+        total_windows = windows * world * args.steps
+        alg_bytes = args.records * args.length * 29 + windows * 12      # per launch, per GPU
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("records") == args.records and tj.get("length") == args.length and tj.get("width") == args.width:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "scored windows/sec (seq+struct, w=%d)" % args.width,
+            "value": total_windows / elapsed,
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, "
+                            "uint8 codes + float32 [n][7] profile, all-scores (f32 seq + f64 struct per window)"
+                            % (args.records, args.length, args.width),
+                "records_per_gpu": args.records, "record_length": args.length, "pfm_width": args.width,
+                "windows_per_gpu_per_step": windows, "mode": "all-scores", "sharding": "records, no collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_profile", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+            },
+        }
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            oracle.build()
+            stride = args.length + 1
+            probe = min(args.records, 500)
+
+            def cpu_run(nrec):
+                c = codes[: nrec * stride].cpu().numpy()
+                p = profile[: nrec * stride].cpu().numpy()
+                t = time.perf_counter()
+                s1 = oracle.stream_seq(c, table)
+                s2 = oracle.stream_struct(p, spssm)
+                return time.perf_counter() - t, s1, s2
+
+            dt, _, _ = cpu_run(probe)
+            nrec = int(max(probe, min(args.records, probe * args.cpu_seconds / max(dt, 1e-6))))
+            dt, ref_seq, ref_st = cpu_run(nrec)
+            nwin = nrec * (args.length - args.width + 1)
+            result["cpu_baseline"] = {
+                "value": nwin / dt, "unit": "windows/s", "cores": oracle.num_threads(), "kind": "port",
+                "sample": "first %d of %d records (%d windows), oracle/pfm_oracle.c stream_seq + stream_struct_f32, "
+                          "OpenMP over positions, %.2f s" % (nrec, args.records, nwin, dt),
+                "host_cpus": os.cpu_count(),
+            }
+            got_seq = out_seq[: nrec * stride].cpu().numpy()
+            got_st = out_st[: nrec * stride].cpu().numpy()
+            nan_ok = bool(np.array_equal(np.isnan(got_seq), np.isnan(ref_seq)))
+            v = ~np.isnan(ref_seq)
+            seq_ok = nan_ok and bool(np.array_equal(got_seq[v].view(np.uint32), ref_seq[v].view(np.uint32)))
+            vs = ~np.isnan(ref_st)
+            st_err = float(np.abs(got_st[vs] - ref_st[vs]).max())
+            result["parity_on_sample"] = {"seq_f32_bit_exact": seq_ok, "struct_max_abs_err": st_err,
+                                          "struct_within_1e-6": bool(st_err <= 1e-6 and np.array_equal(np.isnan(got_st), np.isnan(ref_st)))}
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

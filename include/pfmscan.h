@@ -1,0 +1,176 @@
+/*
+ * pfmscan.h -- C ABI of libpfmscan: MI355X (gfx950) sliding-window PFM scanner.
+ *
+ * This is the drop-in boundary for rnascan's per-position log-odds scoring
+ * path.  Every entry point names the reference interface it replaces (paths
+ * are relative to the upstream morrislab/rnascan checkout, v0.10.2).  Plain
+ * pointers and sizes only; no C++ or torch types.  Loaded with ctypes
+ * (rnascan_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every function returns a status (0 = PFMSCAN_OK, negative = error class);
+ *     the message is read with pfmscan_last_error().  Foreign letters are never
+ *     an error: they score NaN, as `ok = 0` does in _pwm.c:61-66.
+ *   - the caller owns every buffer it passes; the library never frees caller
+ *     memory and never returns memory the caller must free.  Device scratch is
+ *     owned by the ctx, PSSM tables by the motif object.
+ *   - a ctx is bound to one device and may be used by one host thread at a
+ *     time; use one ctx per device / per thread.  No global mutable state.
+ *   - positions are 0-based at this level; rnascan's 1-based inclusive
+ *     Start/End (rnascan.py:264-271, :311) are made in the table layer.
+ *
+ * The packed record stream
+ *   Records are concatenated into one stream of n_pos positions; every record
+ *   is followed by exactly ONE separator position whose code is PFMSCAN_SEP.
+ *     codes    uint8 [n_pos]      letter index 0..6, or PFMSCAN_SEP (7) for a
+ *                                 separator or any letter outside the alphabet
+ *     profile  float/double [n_pos][7] row-major averaged-structure profile
+ *                                 (rnascan.py:296-297 after `del struct['PO']`),
+ *                                 columns already paired with the PSSM's; the
+ *                                 separator row may hold anything finite
+ *   A window is named by the stream position of its first letter.  Windows that
+ *   touch a separator (i.e. would cross a record end) or the end of the stream
+ *   get a NaN sequence score, so they can never be hits; out arrays are
+ *   position-aligned (length n_pos), record r's windows are
+ *   [off_r, off_r + L_r - m + 1).  Base pointers must be 16-byte aligned.
+ */
+#ifndef PFMSCAN_H
+#define PFMSCAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFMSCAN_ABI_VERSION 1
+#define PFMSCAN_NCODE   8      /* columns of a letter table */
+#define PFMSCAN_SEP     7      /* separator / foreign-letter code */
+#define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
+#define PFMSCAN_MAX_M   64     /* widest PFM accepted */
+
+#define PFMSCAN_OK          0
+#define PFMSCAN_E_BADARG   -1  /* NULL / negative / inconsistent argument   -> ValueError */
+#define PFMSCAN_E_BADSHAPE -2  /* width out of range, misaligned pointer     -> ValueError (_pwm.c:96-113) */
+#define PFMSCAN_E_OOM      -3  /* host or device allocation failed           -> MemoryError (_pwm.c:27-31) */
+#define PFMSCAN_E_HIP      -4  /* HIP runtime error (message has the detail) -> RuntimeError */
+#define PFMSCAN_E_CAPACITY -5  /* hit buffer too small; *n_hits = required   -> retry */
+
+#define PFMSCAN_PROFILE_NONE 0
+#define PFMSCAN_PROFILE_F32  1
+#define PFMSCAN_PROFILE_F64  2
+
+typedef struct pfmscan_ctx pfmscan_ctx;
+typedef struct pfmscan_motif pfmscan_motif;
+
+int pfmscan_abi_version(void);
+
+/* Context bound to HIP device `device` (>= 0).  Fails with PFMSCAN_E_HIP when no
+ * gfx950 device is visible -- there is no CPU fallback behind this ABI. */
+int pfmscan_ctx_create(int device, pfmscan_ctx **out);
+void pfmscan_ctx_destroy(pfmscan_ctx *ctx);
+/* Last error text of `ctx`; ctx == NULL reads the calling thread's last
+ * ctx-less error (a failed pfmscan_ctx_create).  Never NULL. */
+const char *pfmscan_last_error(const pfmscan_ctx *ctx);
+int pfmscan_device_info(const pfmscan_ctx *ctx, int *n_cu, int64_t *hbm_bytes,
+                        char *name, int name_cap);
+int pfmscan_synchronize(pfmscan_ctx *ctx);
+
+/* ---- PSSM operands -------------------------------------------------------
+ * Replaces the per-call list-of-lists -> ndarray conversion of
+ * ExtendedPositionSpecificScoringMatrix._calculate (matrix.py:57-60) and the
+ * `pm = pd.DataFrame(pm)` of scan_averaged_structure (rnascan.py:298-300):
+ * the tables are uploaded once.
+ *   letter_table  double [m][8] or NULL: log-odds per letter code; every column
+ *                 that is not a letter of the alphabet (always column 7) must be
+ *                 NaN.  RNA: columns A,C,G,U = sorted(alphabet.letters)
+ *                 (matrix.py:57), i.e. the column order of _pwm.c:45-60.
+ *   struct_pssm   double [m][7] or NULL: log-odds for the 7 profile columns,
+ *                 paired with the profile's column order by the caller.
+ * At least one must be given; both share the width m (rnascan.py:422-423 joins
+ * on Start AND End, so unequal widths can never produce a combined hit). */
+int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table,
+                         const double *struct_pssm, int m, pfmscan_motif **out);
+void pfmscan_motif_destroy(pfmscan_motif *motif);
+
+/* ---- (iii) of SURVEY 8b: the reference's native entry point ----------------
+ * Replaces `_pwm.calculate(sequence, matrix)` (_pwm.c:72-121, loop :34-68):
+ * ASCII sequence of length s (A/a C/c G/g T/t/U/u; anything else poisons the
+ * windows covering it), matrix double [m][4] in A,C,G,U column order ->
+ * out float [s-m+1] = (float)(fp64 sequential sum).  s < m writes nothing.
+ * Host buffers; runs on the ctx's device. */
+int pfmscan_pwm_calculate(pfmscan_ctx *ctx, const char *sequence, int64_t s,
+                          const double *matrix, int64_t m, float *out);
+
+/* ---- all-scores over a packed stream, device-resident ----------------------
+ * Replaces the window loops of `pssm.search` -> `calculate` (rnascan.py:263,
+ * matrix.py:68-81, _pwm.c:34-68) and of scan_averaged_structure
+ * (rnascan.py:302-307) for every record of the stream in one pass.
+ *   d_codes / d_profile / d_out_* are DEVICE pointers (hipMalloc or torch).
+ *   d_out_seq    float  [n_pos] or NULL: (float)(fp64 sequential sum), NaN for
+ *                windows covering a foreign letter / separator / stream end
+ *   d_out_struct double [n_pos] or NULL: sum_j nan_to_num(dot(profile[p+j], pssm[j]))
+ *                in fp64 (rnascan.py:306); NaN for p + m > n_pos
+ *   stream       hipStream_t, NULL = the ctx's own stream.  Asynchronous. */
+int pfmscan_scan_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                     const uint8_t *d_codes, const void *d_profile,
+                     int profile_dtype, int64_t n_pos, float *d_out_seq,
+                     double *d_out_struct, void *stream);
+
+/* Generic-alphabet letter scan with fp64 output: replaces
+ * ExtendedPositionSpecificScoringMatrix._py_calculate (matrix.py:25-43), which
+ * keeps Python floats (no float32 cast) and gives NaN on an unknown letter. */
+int pfmscan_scan_letters_f64_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                                 const uint8_t *d_codes, int64_t n_pos,
+                                 double *d_out, void *stream);
+
+/* ---- thresholded hits over a packed stream, device-resident ----------------
+ * Replaces `score > threshold` of pssm.search (rnascan.py:263; strict, NaN and
+ * -inf never pass), `if score > minscore` (rnascan.py:310) and, when the motif
+ * has both parts, the inner join of combine() (rnascan.py:422-423):
+ *   hit  <=>  (no letter table  or seq(p)    > thr_seq)
+ *         and (no struct pssm   or struct(p) > thr_struct)
+ * Hits are appended in no particular order:
+ *   d_hit_pos int64 [capacity], d_hit_seq float [capacity] (or NULL),
+ *   d_hit_struct double [capacity] (or NULL), d_hit_count: one uint64 the
+ *   caller zeroes before the call; afterwards it holds the TOTAL number of
+ *   hits, which may exceed capacity (only the first `capacity` are stored). */
+int pfmscan_hits_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                     const uint8_t *d_codes, const void *d_profile,
+                     int profile_dtype, int64_t n_pos, double thr_seq,
+                     double thr_struct, int64_t capacity, int64_t *d_hit_pos,
+                     float *d_hit_seq, double *d_hit_struct,
+                     uint64_t *d_hit_count, void *stream);
+
+/* ---- host-buffer forms ------------------------------------------------------
+ * Same contracts with HOST pointers: the ctx stages H2D into its own device
+ * scratch, launches, copies back and synchronises. */
+int pfmscan_scan_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                      const uint8_t *codes, const void *profile,
+                      int profile_dtype, int64_t n_pos, float *out_seq,
+                      double *out_struct);
+int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                                  const uint8_t *codes, int64_t n_pos, double *out);
+/* Hits come back sorted by position.  PFMSCAN_E_CAPACITY: *n_hits holds the
+ * required capacity, the first `capacity` (unsorted subset) are NOT valid. */
+int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                      const uint8_t *codes, const void *profile,
+                      int profile_dtype, int64_t n_pos, double thr_seq,
+                      double thr_struct, int64_t capacity, int64_t *hit_pos,
+                      float *hit_seq, double *hit_struct, int64_t *n_hits);
+
+/* ---- measurement helper ------------------------------------------------------
+ * Average device time in milliseconds of `iters` back-to-back pfmscan_scan_dev
+ * launches, bracketed by hipEvents on the launch stream (after `warmup`
+ * untimed launches).  Used by bench.py for the roofline figure. */
+int pfmscan_time_scan_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                          const uint8_t *d_codes, const void *d_profile,
+                          int profile_dtype, int64_t n_pos, float *d_out_seq,
+                          double *d_out_struct, void *stream, int warmup,
+                          int iters, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFMSCAN_H */

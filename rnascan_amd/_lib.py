@@ -1,0 +1,286 @@
+"""ctypes binding of libpfmscan.so (include/pfmscan.h).
+
+The product path has no CPU fallback: if the library is missing or no gfx950
+device is visible, everything here raises.  Nothing under ``oracle/`` is ever
+imported from this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpfmscan.so")
+
+OK = 0
+E_BADARG, E_BADSHAPE, E_OOM, E_HIP, E_CAPACITY = -1, -2, -3, -4, -5
+PROFILE_NONE, PROFILE_F32, PROFILE_F64 = 0, 1, 2
+SEP = 7
+NCODE = 8
+NSTRUCT = 7
+MAX_M = 64
+ABI_VERSION = 1
+
+# every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "pfmscan_abi_version", "pfmscan_ctx_create", "pfmscan_ctx_destroy", "pfmscan_last_error",
+    "pfmscan_device_info", "pfmscan_synchronize", "pfmscan_motif_create", "pfmscan_motif_destroy",
+    "pfmscan_pwm_calculate", "pfmscan_scan_dev", "pfmscan_scan_letters_f64_dev", "pfmscan_hits_dev",
+    "pfmscan_scan_host", "pfmscan_scan_letters_f64_host", "pfmscan_hits_host", "pfmscan_time_scan_dev",
+]
+
+
+class CapacityError(RuntimeError):
+    """Hit buffer too small; ``required`` holds the number of hits."""
+
+    def __init__(self, msg, required):
+        RuntimeError.__init__(self, msg)
+        self.required = required
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "rnascan_amd: %s is missing -- build it with `python -m rnascan_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    L.pfmscan_abi_version.restype = i32
+    L.pfmscan_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.pfmscan_ctx_destroy.argtypes = [vp]
+    L.pfmscan_ctx_destroy.restype = None
+    L.pfmscan_last_error.argtypes = [vp]
+    L.pfmscan_last_error.restype = ctypes.c_char_p
+    L.pfmscan_device_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64), ctypes.c_char_p, i32]
+    L.pfmscan_synchronize.argtypes = [vp]
+    L.pfmscan_motif_create.argtypes = [vp, vp, vp, i32, ctypes.POINTER(vp)]
+    L.pfmscan_motif_destroy.argtypes = [vp]
+    L.pfmscan_motif_destroy.restype = None
+    L.pfmscan_pwm_calculate.argtypes = [vp, ctypes.c_char_p, i64, vp, i64, vp]
+    L.pfmscan_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp]
+    L.pfmscan_scan_letters_f64_dev.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.pfmscan_hits_dev.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, vp, vp]
+    L.pfmscan_scan_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp]
+    L.pfmscan_scan_letters_f64_host.argtypes = [vp, vp, vp, i64, vp]
+    L.pfmscan_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_time_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, i32, i32, ctypes.POINTER(dbl)]
+    for name in SYMBOLS:          # every other entry point returns a status
+        if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error"):
+            getattr(L, name).restype = i32
+    if L.pfmscan_abi_version() != ABI_VERSION:
+        raise ImportError("libpfmscan ABI %d, bindings expect %d" % (L.pfmscan_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(int(a))          # raw device address (e.g. torch.Tensor.data_ptr())
+
+
+def _raise(L, ctx, rc, n_hits=None):
+    msg = L.pfmscan_last_error(ctx).decode("utf-8", "replace")
+    if rc in (E_BADARG, E_BADSHAPE):
+        raise ValueError(msg)               # _pwm.c:96-113 raise ValueError
+    if rc == E_OOM:
+        raise MemoryError(msg)              # _pwm.c:27-31
+    if rc == E_CAPACITY:
+        raise CapacityError(msg, n_hits)
+    raise RuntimeError("libpfmscan: " + msg)
+
+
+class Context(object):
+    """One device context (one per GPU / per host thread)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        h = ctypes.c_void_p()
+        rc = self._L.pfmscan_ctx_create(int(device), ctypes.byref(h))
+        if rc != OK:
+            _raise(self._L, None, rc)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pfmscan_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, n_hits=None):
+        if rc != OK:
+            _raise(self._L, self._h, rc, n_hits)
+
+    def device_info(self):
+        n_cu, hbm = ctypes.c_int(), ctypes.c_int64()
+        name = ctypes.create_string_buffer(128)
+        self._check(self._L.pfmscan_device_info(self._h, ctypes.byref(n_cu), ctypes.byref(hbm), name, 128))
+        return {"name": name.value.decode(), "n_cu": n_cu.value, "hbm_bytes": hbm.value}
+
+    def synchronize(self):
+        self._check(self._L.pfmscan_synchronize(self._h))
+
+    # -- PSSM operands ----------------------------------------------------------
+    def motif(self, letter_table=None, struct_pssm=None):
+        return Motif(self, letter_table, struct_pssm)
+
+    # -- _pwm.calculate drop-in -------------------------------------------------
+    def pwm_calculate(self, sequence, matrix):
+        """``_pwm.calculate(sequence, matrix)`` (_pwm.c:79-121) on the GPU."""
+        seq = sequence.encode("ascii") if isinstance(sequence, str) else bytes(sequence)
+        M = np.asarray(matrix)
+        if M.dtype != np.float64:
+            raise ValueError("position-weight matrix should contain floating-point values")
+        if M.ndim != 2:
+            raise ValueError("position-weight matrix has incorrect rank (%d expected 2)" % M.ndim)
+        if M.shape[1] != 4:
+            raise ValueError("position-weight matrix should have four columns (%d columns found)" % M.shape[1])
+        M = np.ascontiguousarray(M)
+        n = len(seq) - M.shape[0] + 1
+        if n < 0:
+            raise MemoryError("failed to create output data")      # _pwm.c:26-31 on a negative shape
+        out = np.empty(n, dtype=np.float32)
+        self._check(self._L.pfmscan_pwm_calculate(self._h, seq, len(seq), _ptr(M), M.shape[0], _ptr(out)))
+        return out
+
+    # -- host-buffer scans ------------------------------------------------------
+    def scan_host(self, motif, codes, profile=None, want_seq=True, want_struct=True):
+        """All window scores of a packed stream -> (seq float32[n] | None, struct float64[n] | None)."""
+        n, codes, profile, dt = _stream_args(motif, codes, profile)
+        out_seq = np.empty(n, dtype=np.float32) if (want_seq and motif.has_letters) else None
+        out_struct = np.empty(n, dtype=np.float64) if (want_struct and motif.has_struct) else None
+        self._check(self._L.pfmscan_scan_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n,
+                                              _ptr(out_seq), _ptr(out_struct)))
+        return out_seq, out_struct
+
+    def scan_letters_f64_host(self, motif, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        out = np.empty(codes.size, dtype=np.float64)
+        self._check(self._L.pfmscan_scan_letters_f64_host(self._h, motif._h, _ptr(codes), codes.size, _ptr(out)))
+        return out
+
+    def hits_host(self, motif, codes, profile=None, thr_seq=-np.inf, thr_struct=-np.inf, capacity=None):
+        """Thresholded hits sorted by position -> (pos int64[k], seq float32[k], struct float64[k]).
+        Grows the buffer and retries when the first guess was too small."""
+        n, codes, profile, dt = _stream_args(motif, codes, profile)
+        cap = int(capacity) if capacity is not None else max(1024, n // 64)
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            sq = np.empty(cap, dtype=np.float32)
+            st = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_hits_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n,
+                                           float(thr_seq), float(thr_struct), cap,
+                                           _ptr(pos), _ptr(sq), _ptr(st), ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
+            return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
+
+    # -- device-pointer scans (pointers are ints, e.g. torch data_ptr()) ----------
+    def scan_dev(self, motif, d_codes, d_profile, profile_dtype, n_pos, d_out_seq, d_out_struct, stream=None):
+        self._check(self._L.pfmscan_scan_dev(self._h, motif._h, _ptr(d_codes), _ptr(d_profile), int(profile_dtype),
+                                             int(n_pos), _ptr(d_out_seq), _ptr(d_out_struct), _ptr(stream)))
+
+    def scan_letters_f64_dev(self, motif, d_codes, n_pos, d_out, stream=None):
+        self._check(self._L.pfmscan_scan_letters_f64_dev(self._h, motif._h, _ptr(d_codes), int(n_pos), _ptr(d_out), _ptr(stream)))
+
+    def hits_dev(self, motif, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity,
+                 d_hit_pos, d_hit_seq, d_hit_struct, d_hit_count, stream=None):
+        self._check(self._L.pfmscan_hits_dev(self._h, motif._h, _ptr(d_codes), _ptr(d_profile), int(profile_dtype),
+                                             int(n_pos), float(thr_seq), float(thr_struct), int(capacity),
+                                             _ptr(d_hit_pos), _ptr(d_hit_seq), _ptr(d_hit_struct), _ptr(d_hit_count),
+                                             _ptr(stream)))
+
+    def time_scan_dev(self, motif, d_codes, d_profile, profile_dtype, n_pos, d_out_seq, d_out_struct,
+                      stream=None, warmup=1, iters=5):
+        ms = ctypes.c_double(0.0)
+        self._check(self._L.pfmscan_time_scan_dev(self._h, motif._h, _ptr(d_codes), _ptr(d_profile), int(profile_dtype),
+                                                  int(n_pos), _ptr(d_out_seq), _ptr(d_out_struct), _ptr(stream),
+                                                  int(warmup), int(iters), ctypes.byref(ms)))
+        return ms.value
+
+
+class Motif(object):
+    """Device-resident PSSM operands: letter table [m][8] and/or structure PSSM [m][7]."""
+
+    def __init__(self, ctx, letter_table=None, struct_pssm=None):
+        self._ctx = ctx
+        self._L = ctx._L
+        lt = None if letter_table is None else np.ascontiguousarray(letter_table, dtype=np.float64)
+        sp = None if struct_pssm is None else np.ascontiguousarray(struct_pssm, dtype=np.float64)
+        if lt is not None and (lt.ndim != 2 or lt.shape[1] != NCODE):
+            raise ValueError("letter_table must be [m][8]")
+        if sp is not None and (sp.ndim != 2 or sp.shape[1] != NSTRUCT):
+            raise ValueError("struct_pssm must be [m][7]")
+        if lt is None and sp is None:
+            raise ValueError("motif needs a letter table and/or a structure PSSM")
+        if lt is not None and sp is not None and lt.shape[0] != sp.shape[0]:
+            raise ValueError("sequence and structure PFMs must have the same width for a combined scan")
+        self.m = int((lt if lt is not None else sp).shape[0])
+        self.has_letters = lt is not None
+        self.has_struct = sp is not None
+        h = ctypes.c_void_p()
+        ctx._check(self._L.pfmscan_motif_create(ctx._h, _ptr(lt), _ptr(sp), self.m, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._L.pfmscan_motif_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stream_args(motif, codes, profile):
+    if motif.has_letters:
+        if codes is None:
+            raise ValueError("motif has a letter table: codes required")
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        n = codes.size
+    dt = PROFILE_NONE
+    if motif.has_struct:
+        if profile is None:
+            raise ValueError("motif has a structure PSSM: profile required")
+        if profile.dtype == np.float32:
+            dt = PROFILE_F32
+        elif profile.dtype == np.float64:
+            dt = PROFILE_F64
+        else:
+            raise ValueError("profile must be float32 or float64")
+        profile = np.ascontiguousarray(profile)
+        if profile.ndim != 2 or profile.shape[1] != NSTRUCT:
+            raise ValueError("profile must be [n_pos][7]")
+        if motif.has_letters and profile.shape[0] != n:
+            raise ValueError("codes and profile disagree on n_pos")
+        n = profile.shape[0]
+    else:
+        profile = None
+    return n, (codes if motif.has_letters else None), profile, dt

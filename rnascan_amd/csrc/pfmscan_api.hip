@@ -1,0 +1,492 @@
+// pfmscan_api.hip -- the C ABI declared in include/pfmscan.h: contexts, PSSM
+// operands, device-pointer launches, host-buffer staging, error reporting.
+// There is no CPU fallback in this library: without a gfx950 device every
+// entry point fails with PFMSCAN_E_HIP.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "pfmscan_internal.hpp"
+
+using namespace pfmscan;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct pfmscan_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Tuning tune;
+    int n_cu = 0;
+    int64_t hbm = 0;
+    char name[128] = {0};
+    DevBuf codes, profile, out_seq, out_struct, hit_pos, hit_seq, hit_struct, count, table;
+};
+
+struct pfmscan_motif {
+    pfmscan_ctx *ctx = nullptr;
+    double *d_letters = nullptr;   // [m][8]
+    double *d_struct = nullptr;    // [m][7]
+    int m = 0;
+    int struct_finite = 0;
+};
+
+static thread_local std::string g_err;
+
+static int fail(pfmscan_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_err = msg;
+    return code;
+}
+
+static int fail_hip(pfmscan_ctx *ctx, hipError_t e, const char *what)
+{
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    return fail(ctx, e == hipErrorOutOfMemory ? PFMSCAN_E_OOM : PFMSCAN_E_HIP, msg);
+}
+
+#define HIP_TRY(ctx, expr)                                         \
+    do {                                                           \
+        hipError_t e__ = (expr);                                   \
+        if (e__ != hipSuccess) return fail_hip((ctx), e__, #expr); \
+    } while (0)
+
+static int ensure(pfmscan_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return PFMSCAN_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, PFMSCAN_E_OOM, std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PFMSCAN_OK;
+}
+
+static void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+extern "C" {
+
+int pfmscan_abi_version(void) { return PFMSCAN_ABI_VERSION; }
+
+int pfmscan_ctx_create(int device, pfmscan_ctx **out)
+{
+    if (!out || device < 0) return fail(nullptr, PFMSCAN_E_BADARG, "pfmscan_ctx_create: bad argument");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, PFMSCAN_E_HIP, std::string("no HIP device visible (") + hipGetErrorString(e) + "); libpfmscan has no CPU fallback");
+    if (device >= n) return fail(nullptr, PFMSCAN_E_BADARG, "pfmscan_ctx_create: device index out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PFMSCAN_E_HIP, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    pfmscan_ctx *ctx = new (std::nothrow) pfmscan_ctx();
+    if (!ctx) return fail(nullptr, PFMSCAN_E_OOM, "out of host memory");
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->hbm = (int64_t)prop.totalGlobalMem;
+    std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail_hip(nullptr, e, "hipStreamCreate");
+    }
+    if (const char *v = std::getenv("PFMSCAN_V")) {
+        int x = std::atoi(v);
+        if (x == 5 || x == 7 || x == 9) ctx->tune.v = x;
+    }
+    if (const char *v = std::getenv("PFMSCAN_DMA")) ctx->tune.dma = std::atoi(v) != 0;
+    *out = ctx;
+    return PFMSCAN_OK;
+}
+
+void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    for (DevBuf *b : {&ctx->codes, &ctx->profile, &ctx->out_seq, &ctx->out_struct, &ctx->hit_pos,
+                      &ctx->hit_seq, &ctx->hit_struct, &ctx->count, &ctx->table})
+        release(*b);
+    delete ctx;
+}
+
+const char *pfmscan_last_error(const pfmscan_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pfmscan_device_info(const pfmscan_ctx *ctx, int *n_cu, int64_t *hbm_bytes, char *name, int name_cap)
+{
+    if (!ctx) return PFMSCAN_E_BADARG;
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm;
+    if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", ctx->name);
+    return PFMSCAN_OK;
+}
+
+int pfmscan_synchronize(pfmscan_ctx *ctx)
+{
+    if (!ctx) return PFMSCAN_E_BADARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFMSCAN_OK;
+}
+
+int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const double *struct_pssm, int m,
+                         pfmscan_motif **out)
+{
+    if (!ctx || !out) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_motif_create: NULL argument");
+    *out = nullptr;
+    if (!letter_table && !struct_pssm) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_motif_create: no table given");
+    if (m < 1 || m > PFMSCAN_MAX_M)
+        return fail(ctx, PFMSCAN_E_BADSHAPE, "PFM width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    if (letter_table) {
+        for (int j = 0; j < m; ++j)
+            if (!std::isnan(letter_table[j * 8 + PFMSCAN_SEP]))
+                return fail(ctx, PFMSCAN_E_BADSHAPE, "letter_table column 7 (separator / foreign letter) must be NaN");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pfmscan_motif *mo = new (std::nothrow) pfmscan_motif();
+    if (!mo) return fail(ctx, PFMSCAN_E_OOM, "out of host memory");
+    mo->ctx = ctx;
+    mo->m = m;
+    hipError_t e = hipSuccess;
+    if (letter_table) {
+        e = hipMalloc((void **)&mo->d_letters, sizeof(double) * m * 8);
+        if (e == hipSuccess) e = hipMemcpy(mo->d_letters, letter_table, sizeof(double) * m * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && struct_pssm) {
+        mo->struct_finite = 1;
+        for (int i = 0; i < m * 7; ++i)
+            if (!std::isfinite(struct_pssm[i])) mo->struct_finite = 0;
+        e = hipMalloc((void **)&mo->d_struct, sizeof(double) * m * 7);
+        if (e == hipSuccess) e = hipMemcpy(mo->d_struct, struct_pssm, sizeof(double) * m * 7, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        pfmscan_motif_destroy(mo);
+        return fail_hip(ctx, e, "uploading PSSM tables");
+    }
+    if (std::getenv("PFMSCAN_FORCE_GENERIC")) mo->struct_finite = 0;
+    *out = mo;
+    return PFMSCAN_OK;
+}
+
+void pfmscan_motif_destroy(pfmscan_motif *mo)
+{
+    if (!mo) return;
+    if (mo->ctx) (void)hipSetDevice(mo->ctx->device);
+    if (mo->d_letters) (void)hipFree(mo->d_letters);
+    if (mo->d_struct) (void)hipFree(mo->d_struct);
+    delete mo;
+}
+
+}  // extern "C"
+
+// ---- shared argument checking + launch --------------------------------------
+static int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
+                          int profile_dtype, int64_t n_pos, ScanArgs &a)
+{
+    if (!ctx || !mo) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
+    if (mo->ctx != ctx) return fail(ctx, PFMSCAN_E_BADARG, "motif belongs to another ctx");
+    if (n_pos < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
+    if (mo->d_letters && !d_codes && n_pos > 0) return fail(ctx, PFMSCAN_E_BADARG, "motif has a letter table but codes is NULL");
+    if (mo->d_struct) {
+        if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
+            return fail(ctx, PFMSCAN_E_BADARG, "motif has a structure PSSM: profile_dtype must be F32 or F64");
+        if (!d_profile && n_pos > 0) return fail(ctx, PFMSCAN_E_BADARG, "motif has a structure PSSM but profile is NULL");
+    }
+    if (misaligned(d_codes) || misaligned(d_profile)) return fail(ctx, PFMSCAN_E_BADSHAPE, "stream base pointers must be 16-byte aligned");
+    std::memset(&a, 0, sizeof(a));
+    a.codes = d_codes;
+    a.profile = mo->d_struct ? d_profile : nullptr;
+    a.profile_dtype = profile_dtype;
+    a.n_pos = n_pos;
+    a.letter_table = mo->d_letters;
+    a.struct_pssm = mo->d_struct;
+    a.m = mo->m;
+    a.struct_finite = mo->struct_finite;
+    return PFMSCAN_OK;
+}
+
+static int do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const char *what = "";
+    hipError_t e = launch_scan(a, ctx->tune, stream ? (hipStream_t)stream : ctx->stream, &what);
+    if (e != hipSuccess) return fail_hip(ctx, e, what);
+    return PFMSCAN_OK;
+}
+
+extern "C" {
+
+int pfmscan_scan_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
+                     int profile_dtype, int64_t n_pos, float *d_out_seq, double *d_out_struct, void *stream)
+{
+    ScanArgs a;
+    int rc = check_and_fill(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, a);
+    if (rc) return rc;
+    if (!d_out_seq && !d_out_struct) return fail(ctx, PFMSCAN_E_BADARG, "no output array given");
+    if (d_out_seq && !mo->d_letters) return fail(ctx, PFMSCAN_E_BADARG, "out_seq requested but the motif has no letter table");
+    if (d_out_struct && !mo->d_struct) return fail(ctx, PFMSCAN_E_BADARG, "out_struct requested but the motif has no structure PSSM");
+    if (misaligned(d_out_seq) || misaligned(d_out_struct)) return fail(ctx, PFMSCAN_E_BADSHAPE, "output pointers must be 16-byte aligned");
+    a.out_seq = d_out_seq;
+    a.out_struct = d_out_struct;
+    if (mo->d_struct && !d_out_struct) {
+        // sequence scores only from a combined motif: run the letters kernel alone
+        a.struct_pssm = nullptr;
+        a.profile = nullptr;
+    }
+    if (mo->d_struct && d_out_struct && !d_out_seq) a.letter_table = nullptr;   // structure scores only
+    return do_launch(ctx, a, stream);
+}
+
+int pfmscan_scan_letters_f64_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, int64_t n_pos,
+                                 double *d_out, void *stream)
+{
+    ScanArgs a;
+    int rc = check_and_fill(ctx, mo, d_codes, nullptr, PFMSCAN_PROFILE_NONE, n_pos, a);
+    if (rc) return rc;
+    if (!mo->d_letters) return fail(ctx, PFMSCAN_E_BADARG, "motif has no letter table");
+    if (!d_out) return fail(ctx, PFMSCAN_E_BADARG, "no output array given");
+    if (misaligned(d_out)) return fail(ctx, PFMSCAN_E_BADSHAPE, "output pointers must be 16-byte aligned");
+    a.struct_pssm = nullptr;
+    a.profile = nullptr;
+    a.out_letters_f64 = d_out;
+    return do_launch(ctx, a, stream);
+}
+
+int pfmscan_hits_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
+                     int profile_dtype, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
+                     int64_t *d_hit_pos, float *d_hit_seq, double *d_hit_struct, uint64_t *d_hit_count, void *stream)
+{
+    ScanArgs a;
+    int rc = check_and_fill(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, a);
+    if (rc) return rc;
+    if (capacity < 0 || !d_hit_count || (capacity > 0 && !d_hit_pos))
+        return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_hits_dev: bad hit buffers");
+    if (std::isnan(thr_seq) || std::isnan(thr_struct)) return fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
+    a.hits = 1;
+    a.thr_seq = thr_seq;
+    a.thr_struct = thr_struct;
+    a.capacity = capacity;
+    a.hit_pos = d_hit_pos;
+    a.hit_seq = mo->d_letters ? d_hit_seq : nullptr;
+    a.hit_struct = mo->d_struct ? d_hit_struct : nullptr;
+    a.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
+    return do_launch(ctx, a, stream);
+}
+
+// ---- host-buffer forms ---------------------------------------------------------
+static int stage_inputs(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
+                        int profile_dtype, int64_t n_pos)
+{
+    if (mo->d_letters) {
+        if (!codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+        int rc = ensure(ctx, ctx->codes, (size_t)n_pos);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->codes.p, codes, (size_t)n_pos, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (mo->d_struct) {
+        if (!profile) return fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
+        if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
+            return fail(ctx, PFMSCAN_E_BADARG, "profile_dtype must be F32 or F64");
+        size_t bytes = (size_t)n_pos * 7 * (profile_dtype == PFMSCAN_PROFILE_F32 ? 4 : 8);
+        int rc = ensure(ctx, ctx->profile, bytes);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->profile.p, profile, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return PFMSCAN_OK;
+}
+
+int pfmscan_scan_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
+                      int profile_dtype, int64_t n_pos, float *out_seq, double *out_struct)
+{
+    if (!ctx || !mo) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
+    if (n_pos < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
+    if (n_pos == 0) return PFMSCAN_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = stage_inputs(ctx, mo, codes, profile, profile_dtype, n_pos);
+    if (rc) return rc;
+    if (out_seq && (rc = ensure(ctx, ctx->out_seq, (size_t)n_pos * 4))) return rc;
+    if (out_struct && (rc = ensure(ctx, ctx->out_struct, (size_t)n_pos * 8))) return rc;
+    rc = pfmscan_scan_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, profile_dtype, n_pos,
+                          out_seq ? (float *)ctx->out_seq.p : nullptr, out_struct ? (double *)ctx->out_struct.p : nullptr,
+                          ctx->stream);
+    if (rc) return rc;
+    if (out_seq) HIP_TRY(ctx, hipMemcpyAsync(out_seq, ctx->out_seq.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_struct) HIP_TRY(ctx, hipMemcpyAsync(out_struct, ctx->out_struct.p, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFMSCAN_OK;
+}
+
+int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, int64_t n_pos, double *out)
+{
+    if (!ctx || !mo || !out) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (!mo->d_letters) return fail(ctx, PFMSCAN_E_BADARG, "motif has no letter table");
+    if (n_pos < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
+    if (n_pos == 0) return PFMSCAN_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    int rc = ensure(ctx, ctx->codes, (size_t)n_pos);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->codes.p, codes, (size_t)n_pos, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure(ctx, ctx->out_struct, (size_t)n_pos * 8))) return rc;
+    rc = pfmscan_scan_letters_f64_dev(ctx, mo, (const uint8_t *)ctx->codes.p, n_pos, (double *)ctx->out_struct.p, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out_struct.p, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFMSCAN_OK;
+}
+
+int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
+                      int profile_dtype, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
+                      int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    if (!ctx || !mo || !n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (n_pos < 0 || capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (capacity > 0 && !hit_pos) return fail(ctx, PFMSCAN_E_BADARG, "hit_pos is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = stage_inputs(ctx, mo, codes, profile, profile_dtype, n_pos);
+    if (rc) return rc;
+    if ((rc = ensure(ctx, ctx->hit_pos, (size_t)std::max<int64_t>(capacity, 1) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_seq, (size_t)std::max<int64_t>(capacity, 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_struct, (size_t)std::max<int64_t>(capacity, 1) * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->count, 8))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->count.p, 0, 8, ctx->stream));
+    rc = pfmscan_hits_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, profile_dtype, n_pos, thr_seq, thr_struct,
+                          capacity, (int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p, (double *)ctx->hit_struct.p,
+                          (uint64_t *)ctx->count.p, ctx->stream);
+    if (rc) return rc;
+    uint64_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_hits = (int64_t)total;
+    if ((int64_t)total > capacity)
+        return fail(ctx, PFMSCAN_E_CAPACITY, "hit buffer too small: " + std::to_string(total) + " hits, capacity " + std::to_string(capacity));
+    if (total == 0) return PFMSCAN_OK;
+    std::vector<int64_t> pos(total);
+    std::vector<float> sq(total);
+    std::vector<double> st(total);
+    HIP_TRY(ctx, hipMemcpy(pos.data(), ctx->hit_pos.p, total * 8, hipMemcpyDeviceToHost));
+    if (mo->d_letters) HIP_TRY(ctx, hipMemcpy(sq.data(), ctx->hit_seq.p, total * 4, hipMemcpyDeviceToHost));
+    if (mo->d_struct) HIP_TRY(ctx, hipMemcpy(st.data(), ctx->hit_struct.p, total * 8, hipMemcpyDeviceToHost));
+    std::vector<int64_t> order(total);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return pos[x] < pos[y]; });
+    for (uint64_t i = 0; i < total; ++i) {
+        hit_pos[i] = pos[order[i]];
+        if (hit_seq) hit_seq[i] = mo->d_letters ? sq[order[i]] : NAN;
+        if (hit_struct) hit_struct[i] = mo->d_struct ? st[order[i]] : NAN;
+    }
+    return PFMSCAN_OK;
+}
+
+// ---- the reference's native entry point ------------------------------------------
+int pfmscan_pwm_calculate(pfmscan_ctx *ctx, const char *sequence, int64_t s, const double *matrix, int64_t m, float *out)
+{
+    if (!ctx) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx");
+    if (!sequence || !matrix || s < 0) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_pwm_calculate: NULL or negative argument");
+    if (m < 1 || m > PFMSCAN_MAX_M)
+        return fail(ctx, PFMSCAN_E_BADSHAPE, "position-weight matrix width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    const int64_t n = s - m + 1;
+    if (n <= 0) return PFMSCAN_OK;
+    if (!out) return fail(ctx, PFMSCAN_E_BADARG, "out is NULL");
+    // letter -> code exactly as the switch of _pwm.c:41-63
+    uint8_t lut[256];
+    std::memset(lut, PFMSCAN_SEP, sizeof(lut));
+    lut[(unsigned char)'A'] = lut[(unsigned char)'a'] = 0;
+    lut[(unsigned char)'C'] = lut[(unsigned char)'c'] = 1;
+    lut[(unsigned char)'G'] = lut[(unsigned char)'g'] = 2;
+    lut[(unsigned char)'T'] = lut[(unsigned char)'t'] = 3;
+    lut[(unsigned char)'U'] = lut[(unsigned char)'u'] = 3;
+    std::vector<uint8_t> codes;
+    std::vector<double> table((size_t)m * 8);
+    try {
+        codes.resize((size_t)s);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, PFMSCAN_E_OOM, "failed to create output data");
+    }
+    for (int64_t i = 0; i < s; ++i) codes[(size_t)i] = lut[(unsigned char)sequence[i]];
+    for (int64_t j = 0; j < m; ++j) {
+        for (int c = 0; c < 4; ++c) table[(size_t)j * 8 + c] = matrix[j * 4 + c];
+        for (int c = 4; c < 8; ++c) table[(size_t)j * 8 + c] = NAN;
+    }
+    pfmscan_motif *mo = nullptr;
+    int rc = pfmscan_motif_create(ctx, table.data(), nullptr, (int)m, &mo);
+    if (rc) return rc;
+    std::vector<float> full;
+    try {
+        full.resize((size_t)s);
+    } catch (const std::bad_alloc &) {
+        pfmscan_motif_destroy(mo);
+        return fail(ctx, PFMSCAN_E_OOM, "failed to create output data");
+    }
+    rc = pfmscan_scan_host(ctx, mo, codes.data(), nullptr, PFMSCAN_PROFILE_NONE, s, full.data(), nullptr);
+    pfmscan_motif_destroy(mo);
+    if (rc) return rc;
+    std::memcpy(out, full.data(), (size_t)n * sizeof(float));
+    return PFMSCAN_OK;
+}
+
+// ---- measurement helper --------------------------------------------------------------
+int pfmscan_time_scan_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
+                          int profile_dtype, int64_t n_pos, float *d_out_seq, double *d_out_struct, void *stream,
+                          int warmup, int iters, double *avg_ms)
+{
+    if (!ctx || !avg_ms || iters < 1 || warmup < 0) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_time_scan_dev: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    for (int i = 0; i < warmup; ++i) {
+        int rc = pfmscan_scan_dev(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, d_out_seq, d_out_struct, st);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) {
+        int rc = pfmscan_scan_dev(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, d_out_seq, d_out_struct, st);
+        if (rc) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return rc;
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / iters;
+    return PFMSCAN_OK;
+}
+
+}  // extern "C"

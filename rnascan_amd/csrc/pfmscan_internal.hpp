@@ -1,0 +1,42 @@
+// pfmscan_internal.hpp -- launch interface between the C ABI (pfmscan_api.hip)
+// and the gfx950 kernels (pfmscan_kernels.hip).  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pfmscan.h"
+
+namespace pfmscan {
+
+struct ScanArgs {
+    const uint8_t *codes;        // [n_pos] device, may be null when the motif has no letter table
+    const void *profile;         // [n_pos][7] float or double, device, may be null
+    int profile_dtype;           // PFMSCAN_PROFILE_*
+    int64_t n_pos;
+    const double *letter_table;  // [m][8] device or null
+    const double *struct_pssm;   // [m][7] device or null
+    int m;
+    int struct_finite;           // every struct_pssm cell finite -> fast path legal
+    // all-scores outputs (position aligned), any may be null
+    float *out_seq;
+    double *out_struct;
+    double *out_letters_f64;     // letter scan with fp64 output (matrix.py:25-43)
+    // hits mode
+    int hits;
+    double thr_seq, thr_struct;
+    int64_t capacity;
+    int64_t *hit_pos;
+    float *hit_seq;
+    double *hit_struct;
+    unsigned long long *hit_count;
+};
+
+// Tuning knobs settable through the environment (read once per ctx), so that
+// variants can be A/B-timed on the GPU box without a rebuild.
+struct Tuning {
+    int v = 7;        // windows per thread in the profile kernel: 5, 7 or 9
+    int dma = 0;      // 1: stage the profile tile with LDS-DMA (global_load_lds)
+};
+
+hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);
+
+}  // namespace pfmscan

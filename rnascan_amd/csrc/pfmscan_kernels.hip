@@ -1,0 +1,443 @@
+// pfmscan_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the sliding-window
+// PFM scanner.  wave64, 256-thread workgroups, fp64 accumulation, no MFMA (the
+// contraction is width x alphabet -- far below one MFMA tile); the design goal
+// is HBM streaming: every input byte is read once with 16-byte-per-lane
+// coalesced loads, every output byte written once with 16-byte-per-lane stores.
+//
+// Two kernel families:
+//
+//  k_letters   codes only (config 2, and the letter-string structure scan).
+//              A thread owns 4 consecutive windows; it loads its own 4 code
+//              bytes plus the (m-1)-byte halo as dwords straight from global
+//              (lane stride 4 B -> one 256-B line pair per wave-instruction),
+//              looks each letter up in an LDS copy of the [m][8] log-odds table
+//              (ds_read_b64, all lanes of an instruction hit the SAME table
+//              row -> at most 8 distinct addresses on 16 distinct banks, no
+//              conflict) and writes its 4 float32 scores as ONE 16-byte store,
+//              so a wave-instruction writes 1 KiB contiguous.
+//
+//  k_profile   codes + averaged-structure profile (config 3, the headline).
+//              A workgroup stages one tile of T = 256*V positions (+ m-1 halo)
+//              of the [n_pos][7] profile through LDS with 16-byte coalesced
+//              loads, then each thread scores V consecutive windows.  V is ODD
+//              so the per-lane LDS row stride (7*V dwords) is odd and the
+//              row reads are bank-conflict free on the linear (DMA-compatible)
+//              image.  The window sum over j is SEQUENTIAL in one lane (fp64),
+//              exactly like the reference loops, so float32 sequence scores are
+//              bit-exact; lanes cooperate on loading, never on the sum.
+//              The thread keeps a sliding window of V profile rows (fp64) in
+//              registers; step j multiplies all V rows by PSSM row j (uniform,
+//              scalar-loaded) and loads ONE new row, so a row is converted
+//              fp32->fp64 once per thread and PSSM rows are read once per step.
+//              Scores leave through an LDS transpose as 16-byte stores.
+//
+// Reference semantics restated here (upstream paths, v0.10.2):
+//   _pwm.c:34-68       score = 0.0 (double); score += M[j][col]; (float)score;
+//                      NaN when any covered letter is foreign (NaN table column)
+//   matrix.py:25-43    same sum, fp64 result, NaN on unknown letter
+//   rnascan.py:302-307 score += nan_to_num(dot(profile[i+j,:], pssm[j,:]))
+//   rnascan.py:263,310 hit <=> score > threshold (strict; NaN/-inf never pass)
+//   rnascan.py:422-423 combined hit <=> both tables hold (id, start, end)
+#include <float.h>
+#include <math.h>
+#include "pfmscan_internal.hpp"
+
+namespace pfmscan {
+
+constexpr int BLOCK = 256;
+constexpr int LET_ITERS = 4;                 // k_letters: 4 x 1024 windows per workgroup
+constexpr int LET_TILE = BLOCK * 4 * LET_ITERS;
+
+// numpy.nan_to_num defaults (rnascan.py:306): NaN -> 0, +-inf -> +-DBL_MAX.
+__device__ __forceinline__ double nan_to_num(double d)
+{
+    double c = fmin(fmax(d, -DBL_MAX), DBL_MAX);
+    return (d != d) ? 0.0 : c;
+}
+
+// 4 code bytes at stream position p (p % 4 == 0); positions >= n_pos read as SEP.
+__device__ __forceinline__ uint32_t load_codes4(const uint8_t *__restrict__ codes, int64_t p, int64_t n_pos)
+{
+    if (p + 4 <= n_pos) return *reinterpret_cast<const uint32_t *>(codes + p);
+    uint32_t w = 0x07070707u;
+    if (p < n_pos) {
+        for (int b = 0; b < 4; ++b)
+            if (p + b < n_pos) w = (w & ~(0xFFu << (8 * b))) | ((uint32_t)codes[p + b] << (8 * b));
+    }
+    return w;
+}
+
+// Append hits of one wave-wide predicate: one atomic per wave-instruction that
+// has any hit (hits are rare at real thresholds, so most ballots are empty).
+__device__ __forceinline__ void emit_hits(bool pass, int64_t p, float sq, double st, const ScanArgs &a)
+{
+    unsigned long long mask = __ballot(pass);
+    if (mask == 0) return;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(a.hit_count, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pass) {
+        unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        if ((int64_t)slot < a.capacity) {
+            a.hit_pos[slot] = p;
+            if (a.hit_seq) a.hit_seq[slot] = sq;
+            if (a.hit_struct) a.hit_struct[slot] = st;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_letters: letter table only.  NDW = dwords of codes a thread may need:
+// bytes 0 .. m+2 relative to its first window -> NDW = 5 / 9 / 17 for
+// m <= 16 / 32 / 64.  OUT_T = float (_pwm.c) or double (matrix.py:25-43).
+// ---------------------------------------------------------------------------
+template <int NDW, typename OUT_T, bool HITS>
+__global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
+{
+    __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
+    const int m = a.m;
+    for (int i = threadIdx.x; i < m * 8; i += BLOCK) tbl[i] = a.letter_table[i];
+    __syncthreads();
+
+    const int64_t n_pos = a.n_pos;
+    const int64_t tile0 = (int64_t)blockIdx.x * LET_TILE;
+    const int ndneed = (m + 2) >> 2;           // highest dword index touched
+    OUT_T *__restrict__ out = reinterpret_cast<OUT_T *>(sizeof(OUT_T) == 4 ? (void *)a.out_seq : (void *)a.out_letters_f64);
+
+#pragma unroll 1
+    for (int it = 0; it < LET_ITERS; ++it) {
+        const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
+        if (p0 >= n_pos) break;
+        uint32_t w[NDW];
+#pragma unroll
+        for (int d = 0; d < NDW; ++d) {
+            uint32_t x = 0x07070707u;
+            if (d <= ndneed) x = load_codes4(a.codes, p0 + 4 * d, n_pos);
+            w[d] = (x & 0x07070707u) << 3;      // byte = code * sizeof(double)
+        }
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
+            if (j0 >= m) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                if (j < m) {
+                    const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int q = j + v;    // byte index relative to p0, compile-time
+                        const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+                        acc[v] += *reinterpret_cast<const double *>(row + b);
+                    }
+                }
+            }
+        }
+        if (HITS) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float sq = (float)acc[v];
+                const double cmp = sizeof(OUT_T) == 4 ? (double)sq : acc[v];
+                const bool pass = (p0 + v < n_pos) && (cmp > a.thr_seq);
+                emit_hits(pass, p0 + v, sq, acc[v], a);
+            }
+        } else if (sizeof(OUT_T) == 4) {
+            float *o = reinterpret_cast<float *>(out) + p0;
+            if (p0 + 4 <= n_pos) {
+                float4 r = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+                *reinterpret_cast<float4 *>(o) = r;
+            } else {
+                for (int v = 0; v < 4; ++v)
+                    if (p0 + v < n_pos) o[v] = (float)acc[v];
+            }
+        } else {
+            double *o = reinterpret_cast<double *>(out) + p0;
+            if (p0 + 4 <= n_pos) {
+                *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
+                *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);
+            } else {
+                for (int v = 0; v < 4; ++v)
+                    if (p0 + v < n_pos) o[v] = acc[v];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_profile
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int round16(int x) { return (x + 15) & ~15; }
+
+template <int V, typename PROF_T>
+struct ProfileLayout {
+    static constexpr int TILE = V * BLOCK;
+    __host__ __device__ static int prof_bytes(int m) { return round16((TILE + m - 1) * 7 * (int)sizeof(PROF_T)); }
+    __host__ __device__ static int code_bytes(int m) { return round16(TILE + m - 1); }
+    __host__ __device__ static int total(int m, bool has_seq)
+    {
+        return prof_bytes(m) + (has_seq ? code_bytes(m) + m * 64 : 0);
+    }
+};
+
+// exact slow path for one window, rows read from the staged LDS tile
+template <typename PROF_T>
+__device__ __noinline__ double struct_window_slow(const PROF_T *prof_lds, int local, const double *__restrict__ pssm, int m)
+{
+    double score = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const PROF_T *r = prof_lds + (local + j) * 7;
+        double d = (double)r[0] * pssm[j * 7];
+        for (int k = 1; k < 7; ++k) d = fma((double)r[k], pssm[j * 7 + k], d);
+        score += nan_to_num(d);
+    }
+    return score;
+}
+
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, bool DMA>
+__global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    constexpr int TILE = L::TILE;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int m = a.m;
+    const int tid = threadIdx.x;
+    const int64_t n_pos = a.n_pos;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    const int prof_bytes = L::prof_bytes(m);
+    PROF_T *prof_lds = reinterpret_cast<PROF_T *>(smem);
+    unsigned char *code_lds = smem + prof_bytes;
+    const char *tseq_lds = reinterpret_cast<const char *>(smem + prof_bytes + L::code_bytes(m));
+
+    // ---- stage the tile: global -> LDS, 16 bytes per lane, coalesced ---------
+    {
+        const int64_t total_bytes = n_pos * 7 * (int64_t)sizeof(PROF_T);
+        const int64_t g0 = tile0 * 7 * (int64_t)sizeof(PROF_T);     // multiple of 16: TILE*28 = 7168*V
+        const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(a.profile) + g0;
+        const int nch = prof_bytes >> 4;
+        if (g0 + prof_bytes <= total_bytes) {
+            if (DMA) {
+                // LDS-DMA: each wave-instruction moves 64 x 16 B into a lane-linear
+                // 1-KiB LDS piece; no VGPR round trip.  Whole 1-KiB pieces first.
+                const int wave = tid >> 6, lane = tid & 63;
+                const int npiece = nch >> 6;
+                for (int pc = wave; pc < npiece; pc += BLOCK / 64) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) uint32_t *)(gsrc + ((size_t)pc << 10) + (lane << 4)),
+                        (__attribute__((address_space(3))) uint32_t *)(smem + ((size_t)pc << 10)),
+                        16, 0, 0);
+                }
+                for (int c = (npiece << 6) + tid; c < nch; c += BLOCK)
+                    reinterpret_cast<uint4 *>(smem)[c] = reinterpret_cast<const uint4 *>(gsrc)[c];
+            } else {
+#pragma unroll 4
+                for (int c = tid; c < nch; c += BLOCK)
+                    reinterpret_cast<uint4 *>(smem)[c] = reinterpret_cast<const uint4 *>(gsrc)[c];
+            }
+        } else {
+            // last tile(s): dword granularity, zero fill past the end of the stream
+            const int ndw = prof_bytes >> 2;
+            const int64_t valid_dw = (total_bytes - g0) >> 2;
+            for (int c = tid; c < ndw; c += BLOCK)
+                reinterpret_cast<uint32_t *>(smem)[c] = (c < valid_dw) ? reinterpret_cast<const uint32_t *>(gsrc)[c] : 0u;
+        }
+        if (HAS_SEQ) {
+            const int ncw = L::code_bytes(m) >> 2;
+            for (int c = tid; c < ncw; c += BLOCK) {
+                uint32_t x = load_codes4(a.codes, tile0 + 4 * (int64_t)c, n_pos);
+                reinterpret_cast<uint32_t *>(code_lds)[c] = (x & 0x07070707u) << 3;
+            }
+            double *t = reinterpret_cast<double *>(smem + prof_bytes + L::code_bytes(m));
+            for (int i = tid; i < m * 8; i += BLOCK) t[i] = a.letter_table[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- score V consecutive windows per thread ------------------------------
+    const int la = tid * V;                       // first local window of this thread
+    double rows[V][7];
+    uint32_t cofs[V];
+    double acc_st[V], acc_sq[V];
+#pragma unroll
+    for (int s = 0; s < V; ++s) {
+        const PROF_T *r = prof_lds + (la + s) * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) rows[s][k] = (double)r[k];
+        cofs[s] = HAS_SEQ ? (uint32_t)code_lds[la + s] : 0u;
+        acc_st[s] = 0.0;
+        acc_sq[s] = 0.0;
+    }
+    const double *__restrict__ pssm = a.struct_pssm;
+
+#pragma unroll 1
+    for (int j0 = 0; j0 < m; j0 += V) {
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            const int j = j0 + u;
+            if (j < m) {                          // wave-uniform
+                double P[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) P[k] = pssm[j * 7 + k];
+                const char *trow = tseq_lds + j * 64;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int slot = (u + v) % V;  // holds stream position la + v + j
+                    double d = rows[slot][0] * P[0];
+#pragma unroll
+                    for (int k = 1; k < 7; ++k) d = fma(rows[slot][k], P[k], d);
+                    acc_st[v] += FINITE ? d : nan_to_num(d);
+                    if (HAS_SEQ) acc_sq[v] += *reinterpret_cast<const double *>(trow + cofs[slot]);
+                }
+                if (j + 1 < m) {                  // slot u is dead now: slide in position la + j + V
+                    const PROF_T *r = prof_lds + (la + j + V) * 7;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) rows[u][k] = (double)r[k];
+                    if (HAS_SEQ) cofs[u] = (uint32_t)code_lds[la + j + V];
+                }
+            }
+        }
+    }
+
+    if (FINITE) {
+        // A finite PSSM makes nan_to_num the identity unless the profile itself
+        // holds NaN/inf (or the sum overflowed); any such event leaves a
+        // non-finite sum behind, and only then is the exact path re-run.
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (!(fabs(acc_st[v]) <= DBL_MAX)) acc_st[v] = struct_window_slow(prof_lds, la + v, pssm, m);
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        if (tile0 + la + v + m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
+
+    if (HITS) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int64_t p = tile0 + la + v;
+            const float sq = (float)acc_sq[v];
+            bool pass = (p < n_pos) && (acc_st[v] > a.thr_struct);
+            if (HAS_SEQ) pass = pass && ((double)sq > a.thr_seq);
+            emit_hits(pass, p, sq, acc_st[v], a);
+        }
+        return;
+    }
+
+    // ---- transpose through LDS, then 16-byte coalesced stores ------------------
+    __syncthreads();                               // every wave is done with the tile
+    float *so = reinterpret_cast<float *>(smem);
+    double *sto = reinterpret_cast<double *>(smem + TILE * 4);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        if (HAS_SEQ) so[la + v] = (float)acc_sq[v];
+        sto[la + v] = acc_st[v];
+    }
+    __syncthreads();
+    if (HAS_SEQ && a.out_seq) {
+        for (int c = tid; c < TILE / 4; c += BLOCK) {
+            const int64_t p = tile0 + 4 * (int64_t)c;
+            if (p + 4 <= n_pos) {
+                *reinterpret_cast<float4 *>(a.out_seq + p) = reinterpret_cast<const float4 *>(so)[c];
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (p + e < n_pos) a.out_seq[p + e] = so[4 * c + e];
+            }
+        }
+    }
+    if (a.out_struct) {
+        for (int c = tid; c < TILE / 2; c += BLOCK) {
+            const int64_t p = tile0 + 2 * (int64_t)c;
+            if (p + 2 <= n_pos) {
+                *reinterpret_cast<double2 *>(a.out_struct + p) = reinterpret_cast<const double2 *>(sto)[c];
+            } else if (p < n_pos) {
+                a.out_struct[p] = sto[2 * c];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+template <int NDW>
+static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
+    if (a.hits)
+        hipLaunchKernelGGL((k_letters<NDW, float, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else if (a.out_letters_f64)
+        hipLaunchKernelGGL((k_letters<NDW, double, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_letters<NDW, float, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_letters(const ScanArgs &a, hipStream_t stream)
+{
+    if (a.m <= 16) return launch_letters_ndw<5>(a, stream);
+    if (a.m <= 32) return launch_letters_ndw<9>(a, stream);
+    return launch_letters_ndw<17>(a, stream);
+}
+
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, bool DMA>
+static hipError_t launch_profile_inst(const ScanArgs &a, hipStream_t stream)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    const unsigned grid = (unsigned)((a.n_pos + L::TILE - 1) / L::TILE);
+    const int lds = L::total(a.m, HAS_SEQ);
+    auto kern = k_profile<V, HAS_SEQ, PROF_T, FINITE, HITS, DMA>;
+    static bool configured = false;     // per instantiation; the attribute is sticky
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int V, bool HAS_SEQ, typename PROF_T, bool DMA>
+static hipError_t launch_profile_v(const ScanArgs &a, hipStream_t stream)
+{
+    if (a.hits) {
+        if (a.struct_finite) return launch_profile_inst<V, HAS_SEQ, PROF_T, true, true, DMA>(a, stream);
+        return launch_profile_inst<V, HAS_SEQ, PROF_T, false, true, DMA>(a, stream);
+    }
+    if (a.struct_finite) return launch_profile_inst<V, HAS_SEQ, PROF_T, true, false, DMA>(a, stream);
+    return launch_profile_inst<V, HAS_SEQ, PROF_T, false, false, DMA>(a, stream);
+}
+
+template <bool HAS_SEQ, typename PROF_T>
+static hipError_t launch_profile_t(const ScanArgs &a, const Tuning &t, hipStream_t stream)
+{
+    if (t.dma) {
+        if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, true>(a, stream);
+        if (t.v == 9) return launch_profile_v<9, HAS_SEQ, PROF_T, true>(a, stream);
+        return launch_profile_v<7, HAS_SEQ, PROF_T, true>(a, stream);
+    }
+    if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, false>(a, stream);
+    if (t.v == 9) return launch_profile_v<9, HAS_SEQ, PROF_T, false>(a, stream);
+    return launch_profile_v<7, HAS_SEQ, PROF_T, false>(a, stream);
+}
+
+hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what)
+{
+    *what = "launch";
+    if (a.n_pos <= 0) return hipSuccess;
+    if (!a.struct_pssm) return launch_letters(a, stream);
+    if (a.out_letters_f64 || a.profile == nullptr) return hipErrorInvalidValue;
+    const bool has_seq = a.letter_table != nullptr;
+    if (a.profile_dtype == PFMSCAN_PROFILE_F64) {
+        // fp64-stored profile (strict-parity storage): 56 B per position in LDS,
+        // so the tile is kept at V = 5 (72 KB, two workgroups per CU).
+        Tuning t5 = t;
+        t5.v = 5;
+        return has_seq ? launch_profile_t<true, double>(a, t5, stream) : launch_profile_t<false, double>(a, t5, stream);
+    }
+    return has_seq ? launch_profile_t<true, float>(a, t, stream) : launch_profile_t<false, float>(a, t, stream);
+}
+
+}  // namespace pfmscan

@@ -1,0 +1,112 @@
+"""Packing of records into the stream layout of include/pfmscan.h.
+
+Every record is followed by ONE separator position (code 7); windows that touch
+it score NaN on the letter path, so no window can span two records and the
+kernels need no per-record metadata.  Offsets are kept on the host to turn a
+stream position back into (record, 0-based start).
+"""
+import numpy as np
+
+SEP = 7
+RNA_LETTERS = "ACGU"                 # sorted(alphabet.letters), matrix.py:57; column order of _pwm.c:45-60
+STRUCT_LETTERS = "EHTBLRM"           # ContextualSecondaryStructure.letters, BioAddons/Alphabet/__init__.py:24
+STRUCT_COLUMNS = "BEHLMRT"           # column order of averaged-structure files (pfmutil.py:62-70 sorts the keys)
+
+_RNA_LUT = np.full(256, SEP, dtype=np.uint8)
+for _i, _pair in enumerate(("Aa", "Cc", "Gg", "TtUu")):   # the switch of _pwm.c:41-63
+    for _ch in _pair:
+        _RNA_LUT[ord(_ch)] = _i
+
+
+def encode_rna(seq):
+    """ASCII nucleotide string -> codes, exactly the letter classes of _pwm.c:41-63
+    (case-insensitive, T == U, everything else foreign)."""
+    b = np.frombuffer(seq.encode("latin-1") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    return _RNA_LUT[b]
+
+
+def letter_lut(letters):
+    """LUT for a generic alphabet; ``_py_calculate`` upper-cases first (matrix.py:31)."""
+    if len(letters) > SEP:
+        raise ValueError("at most 7 letters per alphabet")
+    lut = np.full(256, SEP, dtype=np.uint8)
+    for i, ch in enumerate(letters):
+        lut[ord(ch)] = i
+        lut[ord(ch.lower())] = i
+    return lut
+
+
+def encode_letters(seq, letters):
+    b = np.frombuffer(seq.encode("latin-1") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    return letter_lut(letters)[b]
+
+
+class Stream(object):
+    """A packed batch of records.
+
+    codes    uint8 [n_pos] or None
+    profile  float32/float64 [n_pos][7] or None
+    offsets  int64 [R]   stream position of each record's first letter
+    lengths  int64 [R]   record lengths (without the separator)
+    """
+
+    def __init__(self, codes, profile, offsets, lengths):
+        self.codes = codes
+        self.profile = profile
+        self.offsets = offsets
+        self.lengths = lengths
+        self.n_pos = int(offsets[-1] + lengths[-1] + 1) if len(offsets) else 0
+
+    @property
+    def n_records(self):
+        return len(self.offsets)
+
+    def n_windows(self, m):
+        return int(np.maximum(self.lengths - m + 1, 0).sum())
+
+    def locate(self, pos):
+        """stream positions -> (record index, 0-based start within the record)."""
+        pos = np.asarray(pos, dtype=np.int64)
+        rec = np.searchsorted(self.offsets, pos, side="right") - 1
+        return rec, pos - self.offsets[rec]
+
+    def record_slice(self, r, m):
+        """slice of a position-aligned score array holding record r's windows."""
+        n = max(int(self.lengths[r]) - m + 1, 0)
+        return slice(int(self.offsets[r]), int(self.offsets[r]) + n)
+
+    def window_mask(self, m):
+        """bool [n_pos]: True where a window of width m lies inside one record."""
+        mask = np.zeros(self.n_pos, dtype=bool)
+        for r in range(self.n_records):
+            mask[self.record_slice(r, m)] = True
+        return mask
+
+
+def pack(code_arrays=None, profiles=None, profile_dtype=np.float32):
+    """Pack per-record code arrays and/or per-record [L][7] profiles into a Stream."""
+    src = code_arrays if code_arrays is not None else profiles
+    if src is None:
+        raise ValueError("nothing to pack")
+    lengths = np.array([len(x) for x in src], dtype=np.int64)
+    if code_arrays is not None and profiles is not None:
+        plen = np.array([len(x) for x in profiles], dtype=np.int64)
+        if plen.shape != lengths.shape or np.any(plen != lengths):
+            raise ValueError("sequence and profile lengths differ")
+    offsets = np.zeros(len(lengths), dtype=np.int64)
+    if len(lengths) > 1:
+        offsets[1:] = np.cumsum(lengths[:-1] + 1)
+    n_pos = int((lengths + 1).sum())
+    codes = prof = None
+    if code_arrays is not None:
+        codes = np.full(n_pos, SEP, dtype=np.uint8)
+        for off, c in zip(offsets, code_arrays):
+            codes[off:off + len(c)] = c
+    if profiles is not None:
+        prof = np.zeros((n_pos, 7), dtype=profile_dtype)
+        for off, p in zip(offsets, profiles):
+            p = np.asarray(p)
+            if p.ndim != 2 or p.shape[1] != 7:
+                raise ValueError("profile must be [L][7]")
+            prof[off:off + len(p)] = p
+    return Stream(codes, prof, offsets, lengths)

@@ -1,0 +1,73 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+DATA_DIR = os.path.join(GOLDEN_DIR, "data")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def data_dir():
+    return DATA_DIR
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One device context for the whole GPU session (fails loudly without the library)."""
+    from rnascan_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def assert_f32_bits_equal(got, want):
+    """bit-exact float32 comparison with NaN == NaN (payload/sign of NaN ignored)."""
+    got = np.asarray(got, dtype=np.float32)
+    want = np.asarray(want, dtype=np.float32)
+    assert got.shape == want.shape
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), "NaN pattern differs at %s" % np.flatnonzero(gn != wn)[:10]
+    ok = got.view(np.uint32)[~gn] == want.view(np.uint32)[~wn]
+    assert ok.all(), "float32 bits differ at %s" % np.flatnonzero(~ok)[:10]
+
+
+def assert_struct_close(got, want, tol=1e-6):
+    """structure scores: |d| <= 1e-6 absolute (north star), exact class for NaN/inf,
+    relative 1e-12 for the +-DBL_MAX-sized values nan_to_num produces."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want)), "NaN pattern differs"
+    inf = np.isinf(want)
+    assert np.array_equal(got[inf], want[inf]), "inf pattern differs"
+    fin = np.isfinite(want)
+    big = fin & (np.abs(want) > 1e9)
+    small = fin & ~big
+    if small.any():
+        err = np.abs(got[small] - want[small])
+        assert err.max() <= tol, "max abs err %.3e" % err.max()
+    if big.any():
+        assert np.allclose(got[big], want[big], rtol=1e-12, atol=0), "huge values differ"

@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol
+include/pfmscan.h declares (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "pfmscan.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfmscan_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_bindings_agree():
+    from rnascan_amd import _lib
+    assert header_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    from rnascan_amd import _lib, build
+    build.build_lib()
+    L = _lib.load()
+    assert L.pfmscan_abi_version() == _lib.ABI_VERSION
+    for name in header_symbols():
+        assert getattr(L, name) is not None
+
+
+def test_header_constants_match_bindings():
+    from rnascan_amd import _lib
+    text = open(os.path.join(REPO, "include", "pfmscan.h")).read()
+    consts = dict(re.findall(r"#define\s+(PFMSCAN_[A-Z0-9_]+)\s+(-?\d+)", text))
+    assert int(consts["PFMSCAN_SEP"]) == _lib.SEP
+    assert int(consts["PFMSCAN_NCODE"]) == _lib.NCODE
+    assert int(consts["PFMSCAN_NSTRUCT"]) == _lib.NSTRUCT
+    assert int(consts["PFMSCAN_MAX_M"]) == _lib.MAX_M
+    assert int(consts["PFMSCAN_E_CAPACITY"]) == _lib.E_CAPACITY
+    assert int(consts["PFMSCAN_PROFILE_F64"]) == _lib.PROFILE_F64
+
+
+def test_no_device_fails_loudly():
+    """without a GPU the product path must raise, never fall back to a CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rnascan_amd import _lib
+    with pytest.raises(RuntimeError):
+        _lib.Context(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "rnascan_amd")
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|from\s+\.\.?oracle)|liboracle|pfm_oracle|oracle/_ref|_refpwm", re.M)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not pat.search(src), "%s reaches into oracle/" % f

@@ -1,0 +1,260 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the
+committed goldens.  Integer/position work and float32 sequence scores are
+bit-exact; structure scores within 1e-6 absolute (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import assert_f32_bits_equal, assert_struct_close
+
+pytestmark = pytest.mark.gpu
+
+from rnascan_amd import pack  # noqa: E402
+
+
+def rand_table(rng, m, nletters=4, inf_frac=0.0):
+    T = np.full((m, 8), np.nan)
+    T[:, :nletters] = rng.normal(0, 2, size=(m, nletters))
+    if inf_frac:
+        mask = rng.random((m, nletters)) < inf_frac
+        T[:, :nletters][mask] = -np.inf
+    return T
+
+
+def rand_struct_pssm(rng, m, inf_frac=0.0):
+    P = rng.normal(-1, 2.5, size=(m, 7))
+    if inf_frac:
+        P[rng.random((m, 7)) < inf_frac] = -np.inf
+    return P
+
+
+def rand_stream(rng, n_records, lo, hi, foreign=0.002, zero_snap=True, dtype=np.float32):
+    codes, profs = [], []
+    for _ in range(n_records):
+        L = int(rng.integers(lo, hi + 1))
+        c = rng.integers(0, 4, size=L).astype(np.uint8)
+        c[rng.random(L) < foreign] = 7
+        p = rng.dirichlet(np.full(7, 0.3), size=L) if L else np.zeros((0, 7))
+        if zero_snap and L:
+            p[p < 0.02] = 0.0
+            p /= p.sum(axis=1, keepdims=True)
+        codes.append(c)
+        profs.append(p.astype(dtype))
+    return pack.pack(codes, profs, profile_dtype=dtype)
+
+
+# ---------------------------------------------------------------------------
+# _pwm.calculate drop-in
+# ---------------------------------------------------------------------------
+def test_pwm_calculate_goldens(ctx, golden):
+    for case in golden["pwm"]:
+        M = np.array(case["matrix"], dtype=np.float64).reshape(-1, 4)
+        got = ctx.pwm_calculate(case["sequence"], M)
+        assert_f32_bits_equal(got, np.array(case["scores"], dtype=np.float32))
+
+
+def test_pwm_calculate_shorter_than_width(ctx, golden):
+    assert golden["pwm_shorter_than_m_minus_1_raises"] == "MemoryError"
+    with pytest.raises(MemoryError):
+        ctx.pwm_calculate("ACG", np.zeros((8, 4)))
+    assert ctx.pwm_calculate("ACGUACG", np.zeros((8, 4))).shape == (0,)
+
+
+def test_pwm_calculate_argument_errors(ctx):
+    with pytest.raises(ValueError):
+        ctx.pwm_calculate("ACGU", np.zeros((2, 4), dtype=np.float32))      # _pwm.c:96-100
+    with pytest.raises(ValueError):
+        ctx.pwm_calculate("ACGU", np.zeros((2, 3)))                        # _pwm.c:107-112
+    with pytest.raises(ValueError):
+        ctx.pwm_calculate("ACGU", np.zeros(4))                             # _pwm.c:101-106
+    with pytest.raises(ValueError):
+        ctx.pwm_calculate("A" * 100, np.zeros((65, 4)))                    # wider than PFMSCAN_MAX_M
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8, 12, 15, 16, 17, 18, 31, 32, 33, 48, 64])
+def test_pwm_calculate_vs_oracle_widths(ctx, oracle, m):
+    rng = np.random.default_rng(1000 + m)
+    letters = np.array(list("ACGUacgutTN-"))
+    for L in (m, m + 1, m + 3, 255, 1024, 1027, 4096 + 5, 20011):
+        seq = "".join(rng.choice(letters, size=L, p=[.2, .2, .2, .2, .03, .03, .03, .03, .03, .02, .02, .01]))
+        M = rng.normal(0, 3, size=(m, 4))
+        assert_f32_bits_equal(ctx.pwm_calculate(seq, M), oracle.pwm_calculate(seq, M))
+
+
+def test_calculate_route_golden(ctx, golden):
+    g = golden["calculate_route"]
+    M = np.array([[g["pssm"][l][i] for l in "ACGU"] for i in range(len(g["pssm"]["A"]))])
+    assert_f32_bits_equal(ctx.pwm_calculate(g["sequence"], M), np.array(g["scores"], dtype=np.float32))
+    one = ctx.pwm_calculate(g["single_window_sequence"], M)
+    assert one.shape == (1,) and float(one[0]) == g["single_window_score"]
+
+
+# ---------------------------------------------------------------------------
+# generic-alphabet letter scan, fp64 out (matrix.py:25-43)
+# ---------------------------------------------------------------------------
+def test_py_calculate_goldens(ctx, golden):
+    for case in golden["py_calculate"]:
+        letters = case["letters"]
+        T = np.full((len(case["table"]), 8), np.nan)
+        T[:, :len(letters)] = np.array(case["table"], dtype=np.float64)
+        m = case["m"]
+        motif = ctx.motif(letter_table=T[:m])
+        codes = pack.pack([pack.encode_letters(case["sequence"], letters)]).codes
+        got = ctx.scan_letters_f64_host(motif, codes)[: max(len(case["sequence"]) - m + 1, 0)]
+        want = np.array(case["scores"], dtype=np.float64)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])      # fp64 sequential sum: exact
+        motif.close()
+
+
+# ---------------------------------------------------------------------------
+# packed-stream scans vs the oracle
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [1, 7, 8, 12, 13, 18, 30, 64])
+@pytest.mark.parametrize("inf_frac", [0.0, 0.15])
+def test_stream_seqstruct_vs_oracle(ctx, oracle, m, inf_frac):
+    rng = np.random.default_rng(7 * m + int(inf_frac * 100))
+    s = rand_stream(rng, 40, 0, 700)
+    T = rand_table(rng, m, 4, inf_frac=inf_frac / 3)
+    P = rand_struct_pssm(rng, m, inf_frac=inf_frac)
+    motif = ctx.motif(T, P)
+    got_seq, got_st = ctx.scan_host(motif, s.codes, s.profile)
+    assert_f32_bits_equal(got_seq, oracle.stream_seq(s.codes, T))
+    assert_struct_close(got_st, oracle.stream_struct(s.profile, P))
+    motif.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_pos_extra", [0, 1, 2, 3, 5, 1791, 1792, 1793])
+def test_stream_tail_sizes(ctx, oracle, dtype, n_pos_extra):
+    """stream lengths around the tile sizes (1024 / 1280 / 1792 / 4096) and tiny streams"""
+    rng = np.random.default_rng(99 + n_pos_extra)
+    m = 12
+    T = rand_table(rng, m)
+    P = rand_struct_pssm(rng, m, inf_frac=0.1)
+    motif = ctx.motif(T, P)
+    for base in (0, 11, 12, 13, 4096):
+        L = base + n_pos_extra
+        if L == 0:
+            continue
+        s = rand_stream(rng, 1, L, L, dtype=dtype)
+        got_seq, got_st = ctx.scan_host(motif, s.codes, s.profile)
+        assert_f32_bits_equal(got_seq, oracle.stream_seq(s.codes, T))
+        assert_struct_close(got_st, oracle.stream_struct(s.profile, P))
+    motif.close()
+
+
+def test_stream_struct_only_and_seq_only(ctx, oracle):
+    rng = np.random.default_rng(5)
+    m = 12
+    s = rand_stream(rng, 25, 50, 900)
+    T, P = rand_table(rng, m), rand_struct_pssm(rng, m)
+    both = ctx.motif(T, P)
+    only_seq = ctx.motif(letter_table=T)
+    only_st = ctx.motif(struct_pssm=P)
+    want_seq, want_st = oracle.stream_seq(s.codes, T), oracle.stream_struct(s.profile, P)
+    a, b = ctx.scan_host(only_seq, s.codes)
+    assert b is None
+    assert_f32_bits_equal(a, want_seq)
+    a, b = ctx.scan_host(only_st, None, s.profile)
+    assert a is None
+    assert_struct_close(b, want_st)
+    a, b = ctx.scan_host(both, s.codes, s.profile, want_struct=False)
+    assert_f32_bits_equal(a, want_seq)
+    a, b = ctx.scan_host(both, s.codes, s.profile, want_seq=False)
+    assert_struct_close(b, want_st)
+
+
+def test_profile_with_nonfinite_values_takes_exact_path(ctx, oracle):
+    """finite PSSM -> fast kernel; NaN/inf planted in the PROFILE must still follow
+    nan_to_num per row-dot (rnascan.py:306)"""
+    rng = np.random.default_rng(17)
+    m = 12
+    s = rand_stream(rng, 6, 300, 600)
+    idx = rng.integers(0, s.n_pos, size=25)
+    s.profile[idx[:10], rng.integers(0, 7, size=10)] = np.nan
+    s.profile[idx[10:18], rng.integers(0, 7, size=8)] = np.inf
+    s.profile[idx[18:], rng.integers(0, 7, size=7)] = -np.inf
+    P = rand_struct_pssm(rng, m)
+    motif = ctx.motif(struct_pssm=P)
+    _, got = ctx.scan_host(motif, None, s.profile)
+    assert_struct_close(got, oracle.stream_struct(s.profile, P))
+
+
+def test_scan_averaged_structure_goldens(ctx, golden, data_dir):
+    """the reference's own scan_averaged_structure output (rnascan.py:293-315)"""
+    import os
+    for case in golden["scan_averaged_structure"]:
+        if case["profile_file"]:
+            rows = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(data_dir, case["profile_file"]))][1:]
+            prof = np.array([[float(x) for x in r[1:]] for r in rows])
+        else:
+            prof = np.array(case["profile"], dtype=np.float64)
+        P = np.array(case["pssm"], dtype=np.float64)
+        m = P.shape[0]
+        motif = ctx.motif(struct_pssm=P)
+        s = pack.pack(profiles=[prof], profile_dtype=np.float64)
+        _, got = ctx.scan_host(motif, None, s.profile)
+        got = got[: prof.shape[0] - m + 1]
+        keep = got > case["minscore"]                       # rnascan.py:310, strict
+        starts = np.flatnonzero(keep) + 1                   # 1-based
+        want = case["rows"]
+        assert [r[0] for r in want] == starts.tolist()
+        assert [r[1] for r in want] == (starts + m - 1).tolist()
+        assert_struct_close(got[keep], np.array([r[2] for r in want]))
+        # float32-stored profile (the headline storage): same hits at the reference's numbers
+        s32 = pack.pack(profiles=[prof], profile_dtype=np.float32)
+        _, got32 = ctx.scan_host(motif, None, s32.profile)
+        got32 = got32[: prof.shape[0] - m + 1]
+        assert_struct_close(got32[keep], np.array([r[2] for r in want]), tol=2e-6)
+        motif.close()
+
+
+# ---------------------------------------------------------------------------
+# hits mode
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("thr", [-np.inf, -5.0, 0.0, 6.0])
+def test_hits_vs_oracle(ctx, oracle, thr):
+    rng = np.random.default_rng(31)
+    m = 8
+    s = rand_stream(rng, 60, 10, 1500)
+    T, P = rand_table(rng, m), rand_struct_pssm(rng, m) * 0.3 + 1.0
+    both = ctx.motif(T, P)
+    want_seq, want_st = oracle.stream_seq(s.codes, T), oracle.stream_struct(s.profile, P)
+    pos, sq, st = ctx.hits_host(both, s.codes, s.profile, thr_seq=thr, thr_struct=thr)
+    want_pos = oracle.stream_hits(want_seq, want_st, thr, thr)
+    assert np.array_equal(pos, want_pos)                    # integer positions: exact
+    assert_f32_bits_equal(sq, want_seq[want_pos])
+    assert_struct_close(st, want_st[want_pos])
+    # sequence-only hits (config 2 hits mode)
+    only = ctx.motif(letter_table=T)
+    pos, sq, st = ctx.hits_host(only, s.codes, thr_seq=thr)
+    want_pos = oracle.stream_hits(want_seq, None, thr, thr)
+    assert np.array_equal(pos, want_pos) and st is None
+    assert_f32_bits_equal(sq, want_seq[want_pos])
+
+
+def test_hits_capacity_protocol(ctx, oracle):
+    from rnascan_amd import _lib
+    rng = np.random.default_rng(3)
+    s = rand_stream(rng, 10, 500, 800)
+    T = rand_table(rng, 8)
+    motif = ctx.motif(letter_table=T)
+    want = oracle.stream_hits(oracle.stream_seq(s.codes, T), None, 0.0, 0.0)
+    with pytest.raises(_lib.CapacityError) as e:
+        ctx.hits_host(motif, s.codes, thr_seq=0.0, capacity=3)
+    assert e.value.required == len(want)
+    pos, _, _ = ctx.hits_host(motif, s.codes, thr_seq=0.0, capacity=len(want))
+    assert np.array_equal(pos, want)
+
+
+def test_no_window_spans_two_records(ctx):
+    """separator semantics: every window touching a record end scores NaN"""
+    rng = np.random.default_rng(8)
+    m = 12
+    s = rand_stream(rng, 30, 0, 40, foreign=0.0)
+    T = rand_table(rng, m)
+    motif = ctx.motif(letter_table=T)
+    got, _ = ctx.scan_host(motif, s.codes)
+    mask = s.window_mask(m)
+    assert np.isnan(got[~mask]).all()
+    assert not np.isnan(got[mask]).any()
