@@ -104,10 +104,18 @@ def main():
     table, spssm = make_pssms(args.width)
     motif = ctx.motif(table, spssm)
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank)
-    out_seq = torch.empty(n_pos, dtype=torch.float32, device=dev)
-    out_st = torch.empty(n_pos, dtype=torch.float64, device=dev)
+    # zero-filled (touched) outputs: first-touch of fresh device pages would otherwise
+    # land in the first kernel launches and skew the per-kernel average rocprof reports
+    out_seq = torch.zeros(n_pos, dtype=torch.float32, device=dev)
+    out_st = torch.zeros(n_pos, dtype=torch.float64, device=dev)
     windows = args.records * (args.length - args.width + 1)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) torch stream: the ABI reads stream NULL as "the ctx's own
+    # stream", and the HIP events below must sit on the stream the kernel runs on
+    torch.cuda.synchronize()                 # generation ran on the default stream: finish it first
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def step():
         ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos,

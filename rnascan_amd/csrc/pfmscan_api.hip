@@ -118,9 +118,12 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     }
     if (const char *v = std::getenv("PFMSCAN_V")) {
         int x = std::atoi(v);
-        if (x == 5 || x == 7 || x == 9) ctx->tune.v = x;
+        if (x == 3 || x == 5 || x == 7) ctx->tune.v = x;
     }
     if (const char *v = std::getenv("PFMSCAN_DMA")) ctx->tune.dma = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_PIPE")) ctx->tune.pipe = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_BLOCKS_PER_CU")) ctx->tune.blocks_per_cu = std::atoi(v);
+    if (const char *v = std::getenv("PFMSCAN_ABLATE")) ctx->tune.ablate = std::atoi(v);
     *out = ctx;
     return PFMSCAN_OK;
 }
@@ -230,6 +233,7 @@ static int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;
+    a.ablate = ctx->tune.ablate;
     return PFMSCAN_OK;
 }
 

@@ -45,6 +45,9 @@
 namespace pfmscan {
 
 constexpr int BLOCK = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int LET_ITERS = 4;                 // k_letters: 4 x 1024 windows per workgroup
 constexpr int LET_TILE = BLOCK * 4 * LET_ITERS;
 
@@ -166,111 +169,153 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// k_profile
+// k_profile / k_profile_pipe
 // ---------------------------------------------------------------------------
-__host__ __device__ constexpr int round16(int x) { return (x + 15) & ~15; }
+__host__ __device__ constexpr int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 template <int V, typename PROF_T>
 struct ProfileLayout {
     static constexpr int TILE = V * BLOCK;
-    __host__ __device__ static int prof_bytes(int m) { return round16((TILE + m - 1) * 7 * (int)sizeof(PROF_T)); }
-    __host__ __device__ static int code_bytes(int m) { return round16(TILE + m - 1); }
-    __host__ __device__ static int total(int m, bool has_seq)
+    // both regions are whole 1-KiB LDS-DMA pieces (one wave-instruction = 64 x 16 B)
+    __host__ __device__ static constexpr int prof_bytes(int m) { return round_up((TILE + m - 1) * 7 * (int)sizeof(PROF_T), 1024); }
+    __host__ __device__ static constexpr int code_bytes(int m) { return round_up(TILE + m - 1, 1024); }
+    __host__ __device__ static int buf_bytes(int m, bool has_seq) { return prof_bytes(m) + (has_seq ? code_bytes(m) : 0); }
+    __host__ __device__ static int total(int m, bool has_seq, int nbuf)
     {
-        return prof_bytes(m) + (has_seq ? code_bytes(m) + m * 64 : 0);
+        return nbuf * buf_bytes(m, has_seq) + (has_seq ? m * 64 : 0);
     }
 };
 
-// exact slow path for one window, rows read from the staged LDS tile
+// exact per-window path (rows re-read from the staged LDS tile); only reached
+// when the fast path left a non-finite sum behind
 template <typename PROF_T>
-__device__ __noinline__ double struct_window_slow(const PROF_T *prof_lds, int local, const double *__restrict__ pssm, int m)
+__device__ __forceinline__ double struct_window_slow(const PROF_T *prof_lds, int local, const double *__restrict__ pssm, int m)
 {
     double score = 0.0;
+#pragma unroll 1
     for (int j = 0; j < m; ++j) {
         const PROF_T *r = prof_lds + (local + j) * 7;
         double d = (double)r[0] * pssm[j * 7];
+#pragma unroll 1
         for (int k = 1; k < 7; ++k) d = fma((double)r[k], pssm[j * 7 + k], d);
         score += nan_to_num(d);
     }
     return score;
 }
 
-template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, bool DMA>
-__global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
+// LDS-DMA issued through inline asm.  hipcc cannot tell which LDS buffer a
+// `global_load_lds` writes, so with the builtin it drains vmcnt(0) before the
+// next ds_read and the prefetch never overlaps the scoring loop.  Inline asm is
+// invisible to its wait-count pass; the waits are placed by hand instead
+// (dma_wait_all() before the barrier that publishes a buffer).  Untracked
+// entries only make the compiler's own counted vmcnt waits more conservative.
+// `lds_base` must be wave-uniform: the hardware writes LDS[m0 + 16 * lane].
+__device__ __forceinline__ void dma_issue16(const void *gptr, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(gptr), "s"(lds_base)
+                 : "memory");   // m0 is a reserved register: hipcc re-materialises it before each of its own uses
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)p;
+}
+
+// Stage one tile (profile rows [tile0, tile0+TILE+m-1) and their codes) into an
+// LDS buffer.  Interior tiles: LDS-DMA (DMA) or 16-byte register staging;
+// tiles that touch the end of the stream: dword loads with zero / SEP fill.
+// Returns nothing; completion is observed by the caller's vmcnt(0) + barrier.
+template <int V, bool HAS_SEQ, typename PROF_T, int DMA>   // DMA: 0 registers, 1 builtin LDS-DMA, 2 asm LDS-DMA
+__device__ __forceinline__ void stage_tile(const ScanArgs &a, int64_t tile0, unsigned char *buf, int m)
 {
     using L = ProfileLayout<V, PROF_T>;
-    constexpr int TILE = L::TILE;
-    extern __shared__ __align__(16) unsigned char smem[];
-
-    const int m = a.m;
     const int tid = threadIdx.x;
     const int64_t n_pos = a.n_pos;
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const int prof_bytes = L::prof_bytes(m);
-    PROF_T *prof_lds = reinterpret_cast<PROF_T *>(smem);
-    unsigned char *code_lds = smem + prof_bytes;
-    const char *tseq_lds = reinterpret_cast<const char *>(smem + prof_bytes + L::code_bytes(m));
-
-    // ---- stage the tile: global -> LDS, 16 bytes per lane, coalesced ---------
-    {
-        const int64_t total_bytes = n_pos * 7 * (int64_t)sizeof(PROF_T);
-        const int64_t g0 = tile0 * 7 * (int64_t)sizeof(PROF_T);     // multiple of 16: TILE*28 = 7168*V
-        const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(a.profile) + g0;
-        const int nch = prof_bytes >> 4;
-        if (g0 + prof_bytes <= total_bytes) {
-            if (DMA) {
-                // LDS-DMA: each wave-instruction moves 64 x 16 B into a lane-linear
-                // 1-KiB LDS piece; no VGPR round trip.  Whole 1-KiB pieces first.
-                const int wave = tid >> 6, lane = tid & 63;
-                const int npiece = nch >> 6;
-                for (int pc = wave; pc < npiece; pc += BLOCK / 64) {
+    const int code_bytes = L::code_bytes(m);
+    const int64_t total_bytes = n_pos * 7 * (int64_t)sizeof(PROF_T);
+    const int64_t g0 = tile0 * 7 * (int64_t)sizeof(PROF_T);         // multiple of 16: TILE*28 = 7168*V
+    const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(a.profile) + g0;
+    const bool interior = (g0 + prof_bytes <= total_bytes) && (!HAS_SEQ || tile0 + code_bytes <= n_pos);
+    if (interior) {
+        if (DMA == 2) {
+            // each wave-instruction moves 64 x 16 B into a lane-linear 1-KiB LDS piece
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            const int npiece = prof_bytes >> 10;
+            const uint32_t base = lds_addr(buf);
+            for (int pc = wave; pc < npiece; pc += BLOCK / 64)
+                dma_issue16(gsrc + ((size_t)pc << 10) + (lane << 4), base + ((uint32_t)pc << 10));
+            if (HAS_SEQ) {
+                const unsigned char *csrc = a.codes + tile0;
+                const int ncp = code_bytes >> 10;
+                for (int pc = wave; pc < ncp; pc += BLOCK / 64)
+                    dma_issue16(csrc + ((size_t)pc << 10) + (lane << 4), base + (uint32_t)prof_bytes + ((uint32_t)pc << 10));
+            }
+        } else if (DMA == 1) {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int npiece = prof_bytes >> 10;
+            for (int pc = wave; pc < npiece; pc += BLOCK / 64) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) uint32_t *)(gsrc + ((size_t)pc << 10) + (lane << 4)),
+                    (__attribute__((address_space(3))) uint32_t *)(buf + ((size_t)pc << 10)), 16, 0, 0);
+            }
+            if (HAS_SEQ) {
+                const unsigned char *csrc = a.codes + tile0;
+                const int ncp = code_bytes >> 10;
+                for (int pc = wave; pc < ncp; pc += BLOCK / 64) {
                     __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) uint32_t *)(gsrc + ((size_t)pc << 10) + (lane << 4)),
-                        (__attribute__((address_space(3))) uint32_t *)(smem + ((size_t)pc << 10)),
-                        16, 0, 0);
+                        (const __attribute__((address_space(1))) uint32_t *)(csrc + ((size_t)pc << 10) + (lane << 4)),
+                        (__attribute__((address_space(3))) uint32_t *)(buf + prof_bytes + ((size_t)pc << 10)), 16, 0, 0);
                 }
-                for (int c = (npiece << 6) + tid; c < nch; c += BLOCK)
-                    reinterpret_cast<uint4 *>(smem)[c] = reinterpret_cast<const uint4 *>(gsrc)[c];
-            } else {
-#pragma unroll 4
-                for (int c = tid; c < nch; c += BLOCK)
-                    reinterpret_cast<uint4 *>(smem)[c] = reinterpret_cast<const uint4 *>(gsrc)[c];
             }
         } else {
-            // last tile(s): dword granularity, zero fill past the end of the stream
-            const int ndw = prof_bytes >> 2;
-            const int64_t valid_dw = (total_bytes - g0) >> 2;
-            for (int c = tid; c < ndw; c += BLOCK)
-                reinterpret_cast<uint32_t *>(smem)[c] = (c < valid_dw) ? reinterpret_cast<const uint32_t *>(gsrc)[c] : 0u;
-        }
-        if (HAS_SEQ) {
-            const int ncw = L::code_bytes(m) >> 2;
-            for (int c = tid; c < ncw; c += BLOCK) {
-                uint32_t x = load_codes4(a.codes, tile0 + 4 * (int64_t)c, n_pos);
-                reinterpret_cast<uint32_t *>(code_lds)[c] = (x & 0x07070707u) << 3;
+            // register staging, 4 x 16 B per thread in flight per round (measured faster
+            // than issuing all ~9 loads first: 2.68 vs 2.99 ms on C3)
+            const int nch = prof_bytes >> 4;
+            // nontemporal: the stream is read once, keep it out of L2/MALL's way (-8 % on the
+            // no-compute floor, -2 % end to end on C3)
+#pragma unroll 4
+            for (int c = tid; c < nch; c += BLOCK)
+                reinterpret_cast<u32x4 *>(buf)[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(gsrc) + c);
+            if (HAS_SEQ) {
+                const int ncc = code_bytes >> 4;
+                for (int c = tid; c < ncc; c += BLOCK)
+                    reinterpret_cast<uint4 *>(buf + prof_bytes)[c] = reinterpret_cast<const uint4 *>(a.codes + tile0)[c];
             }
-            double *t = reinterpret_cast<double *>(smem + prof_bytes + L::code_bytes(m));
-            for (int i = tid; i < m * 8; i += BLOCK) t[i] = a.letter_table[i];
+        }
+    } else {
+        const int ndw = prof_bytes >> 2;
+        const int64_t valid_dw = (total_bytes - g0) >> 2;
+        for (int c = tid; c < ndw; c += BLOCK)
+            reinterpret_cast<uint32_t *>(buf)[c] = (c < valid_dw) ? reinterpret_cast<const uint32_t *>(gsrc)[c] : 0u;
+        if (HAS_SEQ) {
+            const int ncw = code_bytes >> 2;
+            for (int c = tid; c < ncw; c += BLOCK)
+                reinterpret_cast<uint32_t *>(buf + prof_bytes)[c] = load_codes4(a.codes, tile0 + 4 * (int64_t)c, n_pos);
         }
     }
-    __syncthreads();
+}
 
-    // ---- score V consecutive windows per thread ------------------------------
-    const int la = tid * V;                       // first local window of this thread
+// Score V consecutive windows per thread from a staged tile.  The sum over j is
+// sequential inside one lane (fp64), like the reference loops.
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE>
+__device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsigned char *code_lds, const char *tseq_lds,
+                                             const double *__restrict__ pssm, int m, int la, double (&acc_st)[V],
+                                             double (&acc_sq)[V])
+{
     double rows[V][7];
     uint32_t cofs[V];
-    double acc_st[V], acc_sq[V];
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         const PROF_T *r = prof_lds + (la + s) * 7;
 #pragma unroll
         for (int k = 0; k < 7; ++k) rows[s][k] = (double)r[k];
-        cofs[s] = HAS_SEQ ? (uint32_t)code_lds[la + s] : 0u;
+        cofs[s] = HAS_SEQ ? (((uint32_t)code_lds[la + s] & 7u) << 3) : 0u;
         acc_st[s] = 0.0;
         acc_sq[s] = 0.0;
     }
-    const double *__restrict__ pssm = a.struct_pssm;
-
 #pragma unroll 1
     for (int j0 = 0; j0 < m; j0 += V) {
 #pragma unroll
@@ -284,22 +329,31 @@ __global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     const int slot = (u + v) % V;  // holds stream position la + v + j
-                    double d = rows[slot][0] * P[0];
+                    if (FINITE) {
+                        // every row-dot is finite, nan_to_num is the identity: chain the
+                        // 7 FMAs straight into the window sum (same terms, same order;
+                        // differs from "round the dot, then add" by ~1e-16 relative)
+                        double sacc = acc_st[v];
 #pragma unroll
-                    for (int k = 1; k < 7; ++k) d = fma(rows[slot][k], P[k], d);
-                    acc_st[v] += FINITE ? d : nan_to_num(d);
+                        for (int k = 0; k < 7; ++k) sacc = fma(rows[slot][k], P[k], sacc);
+                        acc_st[v] = sacc;
+                    } else {
+                        double d = rows[slot][0] * P[0];
+#pragma unroll
+                        for (int k = 1; k < 7; ++k) d = fma(rows[slot][k], P[k], d);
+                        acc_st[v] += nan_to_num(d);
+                    }
                     if (HAS_SEQ) acc_sq[v] += *reinterpret_cast<const double *>(trow + cofs[slot]);
                 }
                 if (j + 1 < m) {                  // slot u is dead now: slide in position la + j + V
                     const PROF_T *r = prof_lds + (la + j + V) * 7;
 #pragma unroll
                     for (int k = 0; k < 7; ++k) rows[u][k] = (double)r[k];
-                    if (HAS_SEQ) cofs[u] = (uint32_t)code_lds[la + j + V];
+                    if (HAS_SEQ) cofs[u] = ((uint32_t)code_lds[la + j + V] & 7u) << 3;
                 }
             }
         }
     }
-
     if (FINITE) {
         // A finite PSSM makes nan_to_num the identity unless the profile itself
         // holds NaN/inf (or the sum overflowed); any such event leaves a
@@ -308,11 +362,21 @@ __global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
         for (int v = 0; v < V; ++v)
             if (!(fabs(acc_st[v]) <= DBL_MAX)) acc_st[v] = struct_window_slow(prof_lds, la + v, pssm, m);
     }
+}
+
+// outputs of one tile: hits, or LDS transpose + 16-byte coalesced stores.
+// `stage` may alias the tile buffer (callers barrier before and after).
+template <int V, bool HAS_SEQ, bool HITS>
+__device__ __forceinline__ void emit_tile(const ScanArgs &a, int64_t tile0, int la, double (&acc_st)[V], double (&acc_sq)[V],
+                                          unsigned char *stage)
+{
+    constexpr int TILE = V * BLOCK;
+    const int tid = threadIdx.x;
+    const int64_t n_pos = a.n_pos;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
     for (int v = 0; v < V; ++v)
-        if (tile0 + la + v + m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
-
+        if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
     if (HITS) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -324,11 +388,9 @@ __global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
         }
         return;
     }
-
-    // ---- transpose through LDS, then 16-byte coalesced stores ------------------
     __syncthreads();                               // every wave is done with the tile
-    float *so = reinterpret_cast<float *>(smem);
-    double *sto = reinterpret_cast<double *>(smem + TILE * 4);
+    float *so = reinterpret_cast<float *>(stage);
+    double *sto = reinterpret_cast<double *>(stage + TILE * 4);
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         if (HAS_SEQ) so[la + v] = (float)acc_sq[v];
@@ -339,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
         for (int c = tid; c < TILE / 4; c += BLOCK) {
             const int64_t p = tile0 + 4 * (int64_t)c;
             if (p + 4 <= n_pos) {
-                *reinterpret_cast<float4 *>(a.out_seq + p) = reinterpret_cast<const float4 *>(so)[c];
+                __builtin_nontemporal_store(reinterpret_cast<const f32x4 *>(so)[c], reinterpret_cast<f32x4 *>(a.out_seq + p));
             } else {
                 for (int e = 0; e < 4; ++e)
                     if (p + e < n_pos) a.out_seq[p + e] = so[4 * c + e];
@@ -350,11 +412,82 @@ __global__ __launch_bounds__(BLOCK) void k_profile(const ScanArgs a)
         for (int c = tid; c < TILE / 2; c += BLOCK) {
             const int64_t p = tile0 + 2 * (int64_t)c;
             if (p + 2 <= n_pos) {
-                *reinterpret_cast<double2 *>(a.out_struct + p) = reinterpret_cast<const double2 *>(sto)[c];
+                __builtin_nontemporal_store(reinterpret_cast<const f64x2 *>(sto)[c], reinterpret_cast<f64x2 *>(a.out_struct + p));
             } else if (p < n_pos) {
                 a.out_struct[p] = sto[2 * c];
             }
         }
+    }
+}
+
+// one tile per workgroup; overlap comes from several resident workgroups per CU
+// launch bound = the residency the LDS tile allows (4 workgroups/CU at V=5, 3 at V=7)
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, int DMA>
+__global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_profile(const ScanArgs a)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int m = a.m;
+    const int64_t tile0 = (int64_t)blockIdx.x * L::TILE;
+    const int prof_bytes = L::prof_bytes(m);
+    char *tseq_lds = reinterpret_cast<char *>(smem + L::buf_bytes(m, HAS_SEQ));
+    if (!(a.ablate & 2)) stage_tile<V, HAS_SEQ, PROF_T, DMA>(a, tile0, smem, m);
+    if (HAS_SEQ)
+        for (int i = threadIdx.x; i < m * 8; i += BLOCK) reinterpret_cast<double *>(tseq_lds)[i] = a.letter_table[i];
+    if (DMA == 2) dma_wait_all();
+    __syncthreads();
+    const int la = threadIdx.x * V;
+    double acc_st[V], acc_sq[V];
+    if (a.ablate & 1) {            // timing diagnostic only (PFMSCAN_ABLATE): skip the scoring loop
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            acc_st[v] = (double)reinterpret_cast<const PROF_T *>(smem)[(la + v) * 7];
+            acc_sq[v] = (double)smem[prof_bytes + la + v];
+        }
+    } else {
+        compute_tile<V, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(smem), smem + prof_bytes, tseq_lds,
+                                                 a.struct_pssm, m, la, acc_st, acc_sq);
+    }
+    if (a.ablate & 4) {            // timing diagnostic only: skip the output path (keep the sums alive)
+        double keep = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) keep += acc_st[v] + acc_sq[v];
+        if (keep == 1.2345e300) a.out_struct[0] = keep;
+        return;
+    }
+    emit_tile<V, HAS_SEQ, HITS>(a, tile0, la, acc_st, acc_sq, smem);
+}
+
+// Persistent, double-buffered form: a workgroup walks tiles b, b+G, b+2G, ...
+// and keeps the NEXT tile's LDS-DMA in flight while it scores the current one,
+// so a whole tile (36-50 KB) per workgroup is always outstanding towards HBM.
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
+__global__ __launch_bounds__(BLOCK) void k_profile_pipe(const ScanArgs a, const int n_tiles)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int m = a.m;
+    const int prof_bytes = L::prof_bytes(m);
+    const int buf_bytes = L::buf_bytes(m, HAS_SEQ);
+    char *tseq_lds = reinterpret_cast<char *>(smem + 2 * buf_bytes);
+    if (HAS_SEQ)
+        for (int i = threadIdx.x; i < m * 8; i += BLOCK) reinterpret_cast<double *>(tseq_lds)[i] = a.letter_table[i];
+    const int la = threadIdx.x * V;
+    int t = blockIdx.x;
+    if (t < n_tiles) stage_tile<V, HAS_SEQ, PROF_T, 2>(a, (int64_t)t * L::TILE, smem, m);
+    int cur = 0;
+#pragma unroll 1
+    for (; t < n_tiles; t += gridDim.x) {
+        unsigned char *buf = smem + cur * buf_bytes;
+        dma_wait_all();                            // this wave's share of tile t has landed ...
+        __syncthreads();                           // ... and everybody's; the other buffer is free
+        const int tn = t + gridDim.x;
+        if (tn < n_tiles) stage_tile<V, HAS_SEQ, PROF_T, 2>(a, (int64_t)tn * L::TILE, smem + (cur ^ 1) * buf_bytes, m);
+        double acc_st[V], acc_sq[V];
+        compute_tile<V, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(buf), buf + prof_bytes, tseq_lds,
+                                                 a.struct_pssm, m, la, acc_st, acc_sq);
+        emit_tile<V, HAS_SEQ, HITS>(a, (int64_t)t * L::TILE, la, acc_st, acc_sq, buf);
+        cur ^= 1;
     }
 }
 
@@ -381,12 +514,12 @@ static hipError_t launch_letters(const ScanArgs &a, hipStream_t stream)
     return launch_letters_ndw<17>(a, stream);
 }
 
-template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, bool DMA>
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, int DMA>
 static hipError_t launch_profile_inst(const ScanArgs &a, hipStream_t stream)
 {
     using L = ProfileLayout<V, PROF_T>;
     const unsigned grid = (unsigned)((a.n_pos + L::TILE - 1) / L::TILE);
-    const int lds = L::total(a.m, HAS_SEQ);
+    const int lds = L::total(a.m, HAS_SEQ, 1);
     auto kern = k_profile<V, HAS_SEQ, PROF_T, FINITE, HITS, DMA>;
     static bool configured = false;     // per instantiation; the attribute is sticky
     if (!configured) {
@@ -399,7 +532,38 @@ static hipError_t launch_profile_inst(const ScanArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int V, bool HAS_SEQ, typename PROF_T, bool DMA>
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
+static hipError_t launch_pipe_inst(const ScanArgs &a, const Tuning &t, hipStream_t stream)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    const int64_t n_tiles = (a.n_pos + L::TILE - 1) / L::TILE;
+    const int lds = L::total(a.m, HAS_SEQ, 2);
+    auto kern = k_profile_pipe<V, HAS_SEQ, PROF_T, FINITE, HITS>;
+    static int per_cu = 0;              // per instantiation and LDS size class
+    static int per_cu_lds = -1;
+    if (per_cu_lds != lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, (size_t)lds);
+        if (e != hipSuccess) return e;
+        if (nb < 1) return hipErrorInvalidConfiguration;
+        per_cu = nb;
+        per_cu_lds = lds;
+    }
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int bpc = per_cu;
+    if (t.blocks_per_cu > 0 && t.blocks_per_cu < bpc) bpc = t.blocks_per_cu;
+    int64_t grid = (int64_t)n_cu * bpc;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, a, (int)n_tiles);
+    return hipGetLastError();
+}
+
+template <int V, bool HAS_SEQ, typename PROF_T, int DMA>
 static hipError_t launch_profile_v(const ScanArgs &a, hipStream_t stream)
 {
     if (a.hits) {
@@ -410,17 +574,32 @@ static hipError_t launch_profile_v(const ScanArgs &a, hipStream_t stream)
     return launch_profile_inst<V, HAS_SEQ, PROF_T, false, false, DMA>(a, stream);
 }
 
+template <int V, bool HAS_SEQ, typename PROF_T>
+static hipError_t launch_pipe_v(const ScanArgs &a, const Tuning &t, hipStream_t stream)
+{
+    if (a.hits) {
+        if (a.struct_finite) return launch_pipe_inst<V, HAS_SEQ, PROF_T, true, true>(a, t, stream);
+        return launch_pipe_inst<V, HAS_SEQ, PROF_T, false, true>(a, t, stream);
+    }
+    if (a.struct_finite) return launch_pipe_inst<V, HAS_SEQ, PROF_T, true, false>(a, t, stream);
+    return launch_pipe_inst<V, HAS_SEQ, PROF_T, false, false>(a, t, stream);
+}
+
 template <bool HAS_SEQ, typename PROF_T>
 static hipError_t launch_profile_t(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
-    if (t.dma) {
-        if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, true>(a, stream);
-        if (t.v == 9) return launch_profile_v<9, HAS_SEQ, PROF_T, true>(a, stream);
-        return launch_profile_v<7, HAS_SEQ, PROF_T, true>(a, stream);
+    if (t.pipe) {
+        if (t.v == 3) return launch_pipe_v<3, HAS_SEQ, PROF_T>(a, t, stream);
+        if (t.v == 7) return launch_pipe_v<7, HAS_SEQ, PROF_T>(a, t, stream);
+        return launch_pipe_v<5, HAS_SEQ, PROF_T>(a, t, stream);
     }
-    if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, false>(a, stream);
-    if (t.v == 9) return launch_profile_v<9, HAS_SEQ, PROF_T, false>(a, stream);
-    return launch_profile_v<7, HAS_SEQ, PROF_T, false>(a, stream);
+    if (t.dma) {
+        if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, 2>(a, stream);
+        return launch_profile_v<7, HAS_SEQ, PROF_T, 2>(a, stream);
+    }
+    if (t.v == 3) return launch_profile_v<3, HAS_SEQ, PROF_T, 0>(a, stream);
+    if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, 0>(a, stream);
+    return launch_profile_v<7, HAS_SEQ, PROF_T, 0>(a, stream);
 }
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what)
@@ -434,7 +613,7 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
         // fp64-stored profile (strict-parity storage): 56 B per position in LDS,
         // so the tile is kept at V = 5 (72 KB, two workgroups per CU).
         Tuning t5 = t;
-        t5.v = 5;
+        t5.v = (t.pipe ? 3 : 5);
         return has_seq ? launch_profile_t<true, double>(a, t5, stream) : launch_profile_t<false, double>(a, t5, stream);
     }
     return has_seq ? launch_profile_t<true, float>(a, t, stream) : launch_profile_t<false, float>(a, t, stream);
