@@ -1,0 +1,271 @@
+"""``rnascan`` command line on top of the MI355X engine.
+
+Same options, modes, stderr messages, column layout and TSV output as
+rnascan/rnascan.py (``getoptions`` :44-105, ``_guess_seq_type`` :114-137,
+``main`` :490-576).  Extra options only ADD behaviour: ``--device`` picks the
+GPU, ``--pairing`` chooses how averaged-structure columns are paired with the
+structure PFM (see scanner.struct_matrix), ``--profile-dtype`` the device storage
+of the profiles.  ``-c/--cores`` and ``-x/--debug`` are accepted and
+ignored: there is no process pool, a batch is one kernel launch.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import fasta, pack, pssm as pssm_mod, scanner, shard
+
+__version__ = "0.10.2+mi355x.1"
+
+
+def getoptions(argv=None):
+    desc = "Scan sequence for motif binding sites. Results sent to STDOUT."
+    parser = argparse.ArgumentParser(prog="rnascan", description=desc)
+    parser.add_argument("fastafiles", metavar="FASTA", nargs="*",
+                        help="Input sequence and structure FASTA files")
+    pfm_grp = parser.add_argument_group("PFM options")
+    pfm_grp.add_argument("-p", "--pfm_seq", dest="pfm_seq", type=str, help="Sequence PFM")
+    pfm_grp.add_argument("-q", "--pfm_struct", dest="pfm_struct", type=str, help="Structure PFM")
+    parser.add_argument("-C", "--pseudocount", type=float, dest="pseudocount", default=0,
+                        help="Pseudocount for normalizing PFM. [%(default)s]")
+    parser.add_argument("-m", "--minscore", type=float, dest="minscore", default=6,
+                        help="Minimum score for motif hits. [%(default)s]")
+    parser.add_argument("-t", "--testseq", dest="testseq", default=None,
+                        help=("Supply a test sequence to scan. FASTA files will be ignored. Can supply "
+                              "sequence and structure as single string separated by  comma."))
+    parser.add_argument("-c", "--cores", type=int, default=8, dest="cores",
+                        help="Number of processing cores [%(default)s] (ignored: the scan runs on the GPU)")
+    bg_grp = parser.add_argument_group("Background frequency options")
+    bg_grp.add_argument("-u", "--uniformbg", action="store_true", default=False, dest="uniform_background",
+                        help=("Use uniform background for calculating log-odds [%(default)s]. Default is to "
+                              "compute background from input sequences. This option is mutually exclusive with -B."))
+    bg_grp.add_argument("-g", "--bgonly", action="store_true", default=False, dest="bgonly",
+                        help=("Compute background probabilities from input sequences (STDOUT) and exit. "
+                              "[%(default)s]"))
+    bg_grp.add_argument("-b", "--bg_seq", default=None, dest="bg_seq",
+                        help="Load file of pre-computed background probabilities for nucleotide sequences")
+    bg_grp.add_argument("-B", "--bg_struct", default=None, dest="bg_struct",
+                        help="Load file of pre-computed background probabilities for nucleotide sequences")
+    parser.add_argument("-v", "--version", action="version", version="%(prog)s " + __version__)
+    parser.add_argument("-x", "--debug", action="store_true", default=False, dest="debug",
+                        help="Turn on debug mode (accepted for compatibility; nothing to disable) [%(default)s]")
+    gpu = parser.add_argument_group("MI355X options (not in the reference)")
+    gpu.add_argument("--device", type=int, default=int(os.environ.get("RNASCAN_DEVICE", "0")),
+                     help="HIP device index [%(default)s]")
+    gpu.add_argument("--pairing", choices=["aligned", "positional"], default="aligned",
+                     help=("averaged-structure columns vs structure PFM: 'aligned' pairs by letter, 'positional' "
+                           "reproduces the reference on Python 3 (file order BEHLMRT against EHTBLRM) [%(default)s]"))
+    gpu.add_argument("--profile-dtype", choices=["float64", "float32"], default="float64",
+                     help=("device storage of averaged-structure profiles: float64 reproduces the reference's "
+                           "fp64 scores to ~1e-14, float32 halves the HBM traffic and stays within 1e-6 [%(default)s]"))
+    args = parser.parse_args(argv)
+    if not (args.pfm_seq or args.pfm_struct):
+        parser.error("Must specify PFMs with -p and/or -q")
+    if args.uniform_background and (args.bg_seq or args.bg_struct):
+        parser.error("You cannot set uniform and custom background options at the same time\n")
+    return args
+
+
+def _guess_seq_type(args):
+    """RNA, SS or RNASS (rnascan.py:114-137)."""
+    nfiles = len(args.fastafiles)
+    if nfiles == 2:
+        if not (args.pfm_seq or args.pfm_struct):
+            fasta.eprint("Missing PFMs")
+            sys.exit(1)
+        return "RNASS"
+    if args.pfm_seq and args.pfm_struct and not args.testseq:
+        fasta.eprint("Can't specify two PFMs with one input file")
+        sys.exit(1)
+    elif args.pfm_seq and args.pfm_struct and args.testseq:
+        return "RNASS"
+    elif args.pfm_seq:
+        return "RNA"
+    elif args.pfm_struct:
+        return "SS"
+    fasta.eprint("Must specify PFMs with -p and/or -q")
+    sys.exit(1)
+
+
+def load_motif(pfm_file, pseudocount, letters, background):
+    """rnascan.py:210-235 (same messages)."""
+    motifs_set = {}
+    fasta.eprint("Loading PFM %s" % pfm_file, end="")
+    tic = time.time()
+    try:
+        motifs_set[pssm_mod.motif_id_of(pfm_file)] = pssm_mod.pfm2pssm(pfm_file, pseudocount, letters, background)
+    except ValueError:
+        fasta.eprint("\nFailed to load motif %s" % pfm_file)
+    except KeyError:
+        fasta.eprint("\nFailed to load motif %s" % pfm_file)
+        fasta.eprint("Check that you are using the correct --type")
+        raise
+    fasta.eprint("\b.", end="")
+    sys.stderr.flush()
+    fasta.eprint("done in %0.2f seconds!" % (float(time.time() - tic)))
+    fasta.eprint("Found %d motifs" % len(motifs_set))
+    if len(motifs_set) == 0:
+        raise ValueError("No motifs found.")
+    return motifs_set
+
+
+def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None)):
+    """rnascan.py:335-413: `source` is a FASTA path, a directory of averaged
+    structures, or a fasta.Record (the -t test sequence).  With more than one rank
+    (dist_ctx = (rank, world, torch.distributed)) every rank scans its contiguous
+    share of the records and rank 0 receives the whole table (others get None)."""
+    rank, world, dist = dist_ctx
+    ptype = np.dtype(args.profile_dtype).type
+    if isinstance(source, fasta.Record):
+        df = scanner.scan_records(engine, [source], pssm, letters, args.minscore)
+        df["Sequence_ID"] = "testseq"
+        df["Description"] = ""
+        fasta.eprint("Processed %d sequences" % 1)
+        return df
+    if os.path.isdir(source):
+        fasta.eprint("Scanning averaged secondary structures ")
+        named = scanner.load_profile_dir(source)
+        if len(named) == 0:
+            raise IOError("No averaged structure files found")
+        df = shard.scan_sharded(named, [p.shape[0] for _, _, p in named],
+                                lambda part: scanner.scan_profiles(engine, part, pssm, args.minscore, args.pairing, ptype),
+                                rank, world, dist)
+        fasta.eprint("Processed %d sequences" % len(named))
+        return df
+    fasta.eprint("Scanning sequences ")
+    recs = list(fasta.parse_sequences(source))
+    df = shard.scan_sharded(recs, [len(r.seq) for r in recs],
+                            lambda part: scanner.scan_records(engine, part, pssm, letters, args.minscore),
+                            rank, world, dist)
+    fasta.eprint("Processed %d sequences" % len(recs))
+    return df
+
+
+def _init_distributed(args):
+    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): records are
+    sharded over the ranks, no data-path collective; returns (rank, world, dist)."""
+    rank, world = shard.env_rank_world()
+    if world == 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("RNASCAN_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        args.device = local
+    if not dist.is_initialized():
+        dist.init_process_group(backend)
+    return rank, world, dist
+
+
+def main(argv=None, engine=None, out=None):
+    tic = time.time()
+    out = out or sys.stdout
+    args = getoptions(argv)
+    seq_type = _guess_seq_type(args)
+    testseq_stack = args.testseq.split(",")[::-1] if args.testseq else None
+    own_engine = False
+    seq_results = struct_results = None
+    seq_pssm = struct_pssm = None
+    seq_source = struct_source = None
+
+    def get_engine():
+        nonlocal engine, own_engine
+        if engine is None:
+            engine = scanner.HipEngine(args.device)     # raises without libpfmscan / a gfx950 device
+            own_engine = True
+        return engine
+
+    if seq_type in ("RNA", "RNASS"):
+        bg = None
+        if args.testseq:
+            seq_source = fasta.Record("testseq", "", testseq_stack.pop())
+        else:
+            seq_source = args.fastafiles[0]
+            bg = fasta.load_background(args.bg_seq, args.uniform_background, seq_source, fasta.RNA, not args.bgonly)
+        if args.bgonly:
+            print(dict(bg), file=out)
+            sys.exit()
+        seq_pssm = load_motif(args.pfm_seq, args.pseudocount, fasta.RNA, bg)
+
+    if seq_type in ("SS", "RNASS"):
+        bg = None
+        if args.testseq:
+            struct_source = fasta.Record("testseq", "", testseq_stack.pop())
+        else:
+            struct_source = args.fastafiles[0] if seq_type == "SS" else args.fastafiles[1]
+            bg = fasta.load_background(args.bg_struct, args.uniform_background, struct_source, fasta.STRUCT,
+                                       not args.bgonly)
+        if args.bgonly:
+            print(dict(bg), file=out)
+            sys.exit()
+        struct_pssm = load_motif(args.pfm_struct, args.pseudocount, fasta.STRUCT, bg)
+
+    dist_ctx = _init_distributed(args) if not args.testseq else (0, 1, None)
+    rank, world, dist = dist_ctx
+    eng = get_engine()
+    final = None
+    if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
+        # sequence FASTA + averaged-structure directory: one fused kernel pass (config 3)
+        ptype = np.dtype(args.profile_dtype).type
+        fasta.eprint("Scanning sequences ")
+        recs = list(fasta.parse_sequences(seq_source))
+        fasta.eprint("Processed %d sequences" % len(recs))
+        fasta.eprint("Scanning averaged secondary structures ")
+        named = scanner.load_profile_dir(struct_source)
+        if len(named) == 0:
+            raise IOError("No averaged structure files found")
+        fasta.eprint("Processed %d sequences" % len(named))
+        lens = {sid: p.shape[0] for sid, _, p in named}
+        pairable = (len(lens) == len(named) and len(set(r.id for r in recs)) == len(recs)
+                    and all(lens.get(r.id, len(r.seq)) == len(r.seq) for r in recs)
+                    and len(set(tuple(l) for _, l, _ in named)) == 1)
+        if pairable:
+            final = shard.scan_sharded(
+                recs, [len(r.seq) for r in recs],
+                lambda part: scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore,
+                                                   args.pairing, ptype),
+                rank, world, dist)
+        else:                                  # ids / lengths do not pair one to one: two tables + join
+            seq_results = shard.scan_sharded(
+                recs, [len(r.seq) for r in recs],
+                lambda part: scanner.scan_records(eng, part, seq_pssm, fasta.RNA, args.minscore), rank, world, dist)
+            struct_results = shard.scan_sharded(
+                named, [p.shape[0] for _, _, p in named],
+                lambda part: scanner.scan_profiles(eng, part, struct_pssm, args.minscore, args.pairing, ptype),
+                rank, world, dist)
+            if rank == 0:
+                final = scanner.combine(seq_results, struct_results)
+    else:
+        if seq_type in ("RNA", "RNASS"):
+            seq_results = scan_main(eng, seq_source, seq_pssm, fasta.RNA, args, dist_ctx)
+        if seq_type in ("SS", "RNASS"):
+            struct_results = scan_main(eng, struct_source, struct_pssm, fasta.STRUCT, args, dist_ctx)
+        if rank == 0:
+            if seq_type == "RNASS":
+                final = scanner.combine(seq_results, struct_results)
+            elif seq_type == "RNA":
+                final = seq_results
+            else:
+                final = struct_results
+
+    if rank == 0:
+        scanner._add_match_id(final)
+        final.to_csv(out, sep="\t", index=False)
+    if own_engine:
+        engine.close()
+    if dist is not None:
+        dist.barrier()
+    runtime = float(time.time() - tic)
+    if runtime > 60:
+        fasta.eprint("Done in %0.4f minutes!" % (runtime / 60))
+    else:
+        fasta.eprint("Done in %0.4f seconds!" % (runtime))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,281 @@
+"""Host-side mirror of rnascan's scan layer on top of the HIP engine.
+
+Same names, argument meaning and table layout as the reference functions
+(rnascan/rnascan.py): ``scan`` (:258-275), ``scan_all`` (:278-286),
+``scan_averaged_structure`` (:293-315), ``scan_main`` (:335-413), ``combine``
+(:416-434), ``_add_match_id`` (:329-332) -- but a whole batch of records goes
+through ONE kernel launch instead of one Python loop per window.
+
+The engine is the only thing that computes scores.  ``HipEngine`` (the default
+and the only engine in this package) calls libpfmscan through ctypes and raises
+when the library or the GPU is missing; there is no CPU path here.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+
+from . import _lib, fasta, pack
+from .pssm import PSSM
+
+SEQ_COLUMNS = ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds"]
+
+
+class HipEngine(object):
+    """Scores packed streams on one MI355X through the C ABI (include/pfmscan.h)."""
+
+    def __init__(self, device=0):
+        self.ctx = _lib.Context(device)
+
+    def close(self):
+        self.ctx.close()
+
+    def scan(self, stream, letter_table=None, struct_pssm=None):
+        """all window scores, position aligned -> (float32 seq | None, float64 struct | None)"""
+        motif = self.ctx.motif(letter_table, struct_pssm)
+        try:
+            return self.ctx.scan_host(motif, stream.codes, stream.profile)
+        finally:
+            motif.close()
+
+    def scan_letters_f64(self, stream, letter_table):
+        """generic-alphabet letter scores in fp64 (matrix.py:25-43)"""
+        motif = self.ctx.motif(letter_table, None)
+        try:
+            return self.ctx.scan_letters_f64_host(motif, stream.codes)
+        finally:
+            motif.close()
+
+    def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf):
+        """positions (sorted) whose scores exceed the thresholds -> (pos, seq | None, struct | None)"""
+        motif = self.ctx.motif(letter_table, struct_pssm)
+        try:
+            return self.ctx.hits_host(motif, stream.codes, stream.profile, thr_seq, thr_struct)
+        finally:
+            motif.close()
+
+
+def _first_motif(pssm):
+    """rnascan.py:262 / :298 -- only the FIRST motif of the dict is scanned."""
+    return list(pssm.items())[0]
+
+
+def _select(engine, stream, m, letter_table, struct_pssm, thr_seq, thr_struct):
+    """hits of a stream; an infinite threshold (-m ' -inf') would make every window
+    a hit, so that case takes the all-scores kernel and filters on the host with the
+    same strict `>` (NaN and -inf never pass: rnascan.py:263, :310)."""
+    if np.isneginf(thr_seq) and np.isneginf(thr_struct):
+        sq, st = engine.scan(stream, letter_table, struct_pssm)
+        keep = stream.window_mask(m)
+        if sq is not None:
+            keep &= sq.astype(np.float64) > thr_seq
+        if st is not None:
+            keep &= st > thr_struct
+        pos = np.flatnonzero(keep)
+        return pos, (None if sq is None else sq[pos]), (None if st is None else st[pos])
+    pos, sq, st = engine.hits(stream, letter_table, struct_pssm, thr_seq, thr_struct)
+    if letter_table is None:                 # no codes -> no separator poisoning: drop windows that
+        rec, start = stream.locate(pos)      # run over a record end on the host
+        ok = start + m <= stream.lengths[rec]
+        pos, st = pos[ok], st[ok]
+    return pos, sq, st
+
+
+# ---------------------------------------------------------------------------
+# sequence / letter-string scans
+# ---------------------------------------------------------------------------
+def scan_records(engine, records, pssm, letters, minscore):
+    """Batch form of scan_all (rnascan.py:278-286) + the per-record tagging of
+    scan_main (:401-402): all records in one launch.
+
+    records: iterable of fasta.Record; letters: the alphabet's letters (``GAUC``
+    for RNA, ``EHTBLRM`` for structure strings).  Returns the hit table with the
+    reference's columns, rows in record order then by Start."""
+    motif_id, pm = _first_motif(pssm)
+    m = pm.length
+    is_rna = fasta.is_rna_letters(letters)
+    recs = list(records)
+    seqs = [fasta.preprocess_seq(r.seq, is_rna) for r in recs]
+    if is_rna:
+        order = pack.RNA_LETTERS                               # sorted(alphabet.letters), matrix.py:57
+        codes = [pack.encode_rna(s) for s in seqs]
+    else:
+        order = letters
+        codes = [pack.encode_letters(s, order) for s in seqs]   # _py_calculate upper-cases, matrix.py:31
+    table = pm.letter_table(order)
+    if not recs:
+        return pd.DataFrame(columns=SEQ_COLUMNS)
+    stream = pack.pack(codes)
+    if is_rna:
+        pos, sq, _ = _select(engine, stream, m, table, None, float(minscore), -np.inf)
+        logodds = np.round(sq, 3)                              # round(np.float32, 3) stays float32 (rnascan.py:273)
+    else:
+        full = engine.scan_letters_f64(stream, table)           # Python floats in the reference: fp64, no f32 cast
+        keep = stream.window_mask(m) & (full > float(minscore))
+        pos = np.flatnonzero(keep)
+        logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
+    rec, start = stream.locate(pos)
+    frag = [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
+    ids = [recs[r].id for r in rec.tolist()]
+    desc = [recs[r].description for r in rec.tolist()]
+    return pd.DataFrame({"Sequence_ID": ids, "Description": desc, "Motif_ID": motif_id,
+                         "Start": start + 1, "End": start + m, "Sequence": frag, "LogOdds": logodds},
+                        columns=SEQ_COLUMNS)
+
+
+def scan(engine, pssm, seq, letters, minscore):
+    """rnascan.py:258-275 for one (already preprocessed) sequence string:
+    list of [motif_id, Start, End, fragment, round(score, 3)]."""
+    df = scan_records(engine, [fasta.Record("", "", seq)], pssm, letters, minscore)
+    return [[r.Motif_ID, int(r.Start), int(r.End), r.Sequence, r.LogOdds] for r in df.itertuples()]
+
+
+def scan_all(engine, record, pssm, letters, minscore):
+    """rnascan.py:278-286: one record -> [Motif_ID, Start, End, Sequence, LogOdds] sorted by Start."""
+    df = scan_records(engine, [record], pssm, letters, minscore)
+    return df[["Motif_ID", "Start", "End", "Sequence", "LogOdds"]]
+
+
+# ---------------------------------------------------------------------------
+# averaged-structure scans
+# ---------------------------------------------------------------------------
+def struct_matrix(pm, file_letters, pairing="aligned"):
+    """PSSM operand [m][7] for a profile whose columns are ``file_letters``.
+
+    ``aligned``: column k scores the letter the file says column k holds -- the
+    evident intent and what the reference computed where ``DataFrame(dict)``
+    sorted its keys (Python 2 / old pandas).  ``positional``: column k is paired
+    with the k-th letter the PSSM was filled in (``EHTBLRM``), which is what
+    rnascan.py:300-307 does on Python >= 3.6 / pandas >= 0.23."""
+    if pairing == "aligned":
+        return pm.matrix(file_letters)
+    if pairing == "positional":
+        return pm.matrix(list(pm.keys())[:len(file_letters)])
+    raise ValueError("pairing must be 'aligned' or 'positional'")
+
+
+def scan_profiles(engine, named_profiles, pssm, minscore, pairing="aligned", profile_dtype=np.float32):
+    """Batch form of scan_averaged_structure (rnascan.py:293-315) + the tagging of
+    scan_main (:367-374).  named_profiles: list of (Sequence_ID, letters, [L][7])."""
+    motif_id, pm = _first_motif(pssm)
+    m = pm.length
+    cols = SEQ_COLUMNS
+    if not named_profiles:
+        return pd.DataFrame(columns=cols)
+    letters0 = list(named_profiles[0][1])
+    P = struct_matrix(pm, letters0, pairing)
+    for _, letters, _ in named_profiles:
+        if list(letters) != letters0:
+            raise ValueError("averaged-structure files disagree on their column order")
+    stream = pack.pack(profiles=[p for _, _, p in named_profiles], profile_dtype=profile_dtype)
+    pos, _, st = _select(engine, stream, m, None, P, -np.inf, float(minscore))
+    rec, start = stream.locate(pos)
+    ids = [named_profiles[r][0] for r in rec.tolist()]
+    return pd.DataFrame({"Sequence_ID": ids, "Description": "", "Motif_ID": motif_id, "Start": start + 1,
+                         "End": start + m, "Sequence": ".", "LogOdds": st}, columns=cols)
+
+
+def scan_averaged_structure(engine, struct_file, pssm, minscore, pairing="aligned", profile_dtype=np.float64):
+    """rnascan.py:293-315 for one profile file -> [Motif_ID, Start, End, Sequence, LogOdds]."""
+    letters, prof = fasta.read_profile(struct_file)
+    df = scan_profiles(engine, [("", letters, prof)], pssm, minscore, pairing, profile_dtype)
+    return df[["Motif_ID", "Start", "End", "Sequence", "LogOdds"]]
+
+
+def scan_profile_dir(engine, directory, pssm, minscore, pairing="aligned", profile_dtype=np.float32):
+    """scan_main's directory branch (rnascan.py:348-375, pool form)."""
+    fasta.eprint("Scanning averaged secondary structures ")
+    files = fasta.list_profiles(directory)
+    if len(files) == 0:
+        raise IOError("No averaged structure files found")
+    named = []
+    for sid, path in files:
+        letters, prof = fasta.read_profile(path)
+        named.append((sid, letters, prof))
+    df = scan_profiles(engine, named, pssm, minscore, pairing, profile_dtype)
+    fasta.eprint("Processed %d sequences" % len(named))
+    return df
+
+
+# ---------------------------------------------------------------------------
+# combined scan: one fused pass instead of two tables + a hash join
+# ---------------------------------------------------------------------------
+COMBINED_COLUMNS = ["Sequence_ID", "Description.Seq", "Motif_ID.Seq", "Start", "End", "Sequence.Seq", "LogOdds.Seq",
+                    "Description.Struct", "Motif_ID.Struct", "Sequence.Struct", "LogOdds.Struct", "LogOdds.SeqStruct"]
+
+
+def combine(seq_results, struct_results):
+    """rnascan.py:416-434: inner join on (Sequence_ID, Start, End); the combined
+    score is the sum of the two log-odds (float32 + float64 -> float64)."""
+    result = pd.merge(seq_results, struct_results, on=["Sequence_ID", "Start", "End"])
+    result = result.rename(columns={"Description_x": "Description.Seq", "Description_y": "Description.Struct",
+                                    "Sequence_x": "Sequence.Seq", "Sequence_y": "Sequence.Struct",
+                                    "Motif_ID_x": "Motif_ID.Seq", "Motif_ID_y": "Motif_ID.Struct",
+                                    "LogOdds_x": "LogOdds.Seq", "LogOdds_y": "LogOdds.Struct"})
+    result["LogOdds.SeqStruct"] = result["LogOdds.Seq"] + result["LogOdds.Struct"]
+    return result
+
+
+def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minscore, pairing="aligned",
+                  profile_dtype=np.float32):
+    """Sequence PFM + averaged-structure PFM in ONE kernel pass (config 3).
+
+    Equivalent to ``combine(scan_main(fasta), scan_main(dir))`` for the records
+    that have a profile of the same length under the same Sequence_ID: a window
+    is reported iff seq > minscore AND struct > minscore (rnascan.py:422-433 is
+    an inner join of two independently thresholded tables).  Returns None when
+    the inputs cannot be paired one to one (duplicate ids, length mismatch,
+    unequal PFM widths); callers then take the two-table path."""
+    seq_id, spm = _first_motif(seq_pssm)
+    st_id, tpm = _first_motif(struct_pssm)
+    m = spm.length
+    if tpm.length != m:
+        return None
+    recs = list(records)
+    by_id = {}
+    for sid, letters, prof in named_profiles:
+        if sid in by_id:
+            return None
+        by_id[sid] = (letters, prof)
+    if len(set(r.id for r in recs)) != len(recs):
+        return None
+    pairs = [(r, by_id[r.id]) for r in recs if r.id in by_id]
+    if not pairs:
+        return pd.DataFrame(columns=COMBINED_COLUMNS)
+    letters0 = list(pairs[0][1][0])
+    seqs, codes, profs = [], [], []
+    for r, (letters, prof) in pairs:
+        s = fasta.preprocess_seq(r.seq, True)
+        if len(s) != prof.shape[0] or list(letters) != letters0:
+            return None
+        seqs.append(s)
+        codes.append(pack.encode_rna(s))
+        profs.append(prof)
+    stream = pack.pack(codes, profs, profile_dtype=profile_dtype)
+    table = spm.letter_table(pack.RNA_LETTERS)
+    P = struct_matrix(tpm, letters0, pairing)
+    pos, sq, st = _select(engine, stream, m, table, P, float(minscore), float(minscore))
+    rec, start = stream.locate(pos)
+    rl, sl = rec.tolist(), start.tolist()
+    lo_seq = np.round(sq, 3)
+    df = pd.DataFrame({
+        "Sequence_ID": [pairs[r][0].id for r in rl],
+        "Description.Seq": [pairs[r][0].description for r in rl],
+        "Motif_ID.Seq": seq_id, "Start": start + 1, "End": start + m,
+        "Sequence.Seq": [seqs[r][s:s + m] for r, s in zip(rl, sl)],
+        "LogOdds.Seq": lo_seq, "Description.Struct": "", "Motif_ID.Struct": st_id, "Sequence.Struct": ".",
+        "LogOdds.Struct": st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + st}, columns=COMBINED_COLUMNS)
+    return df
+
+
+def _add_match_id(df):
+    """rnascan.py:329-332"""
+    df["Match_ID"] = list(range(1, df.shape[0] + 1))
+
+
+def load_profile_dir(directory):
+    named = []
+    for sid, path in fasta.list_profiles(directory):
+        letters, prof = fasta.read_profile(path)
+        named.append((sid, letters, prof))
+    return named

@@ -1,0 +1,67 @@
+"""Record sharding over the GPUs of one node.
+
+Records are independent, the PSSM is a <1 KB constant, so N GPUs = N replicas of
+the same kernel on disjoint contiguous record ranges: one process per GPU
+(``torch.distributed``; backend nccl = RCCL on the GPU box, gloo in CPU tests),
+NO collective on the data path.  The only exchange is the gather of the hit
+tables onto rank 0, which keeps file order because the ranges are contiguous and
+the gather concatenates in rank order; ``Match_ID`` is numbered afterwards
+(rnascan.py:329-332).  This replaces the reference's
+``multiprocessing.Pool.map`` fan-out (rnascan.py:363-366, :388-395).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+
+
+def partition(lengths, world):
+    """Contiguous record ranges [(lo, hi), ...] (one per rank) balanced by the
+    number of stream positions sum(L_r + 1); ranges may be empty."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    if world <= 0:
+        raise ValueError("world must be positive")
+    cost = np.cumsum(lengths + 1)
+    total = int(cost[-1]) if n else 0
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        cut = int(np.searchsorted(cost, target, side="left"))
+        if cut < n and (cut == 0 or abs(cost[cut] - target) < abs(cost[cut - 1] - target)):
+            cut += 1
+        bounds.append(max(bounds[-1], min(cut, n)))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def gather_frames(df, rank, world, dist=None):
+    """Concatenate per-rank hit tables on rank 0 in rank order (= file order).
+    Returns the full table on rank 0 and None elsewhere."""
+    if world == 1:
+        return df
+    if dist is None:
+        import torch.distributed as dist
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(df, bucket, dst=0)
+    if rank != 0:
+        return None
+    frames = [f for f in bucket if f is not None and len(f)]
+    if not frames:
+        return bucket[0]
+    return pd.concat(frames, ignore_index=True)
+
+
+def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None):
+    """Run ``scan_fn(items[lo:hi])`` on this rank's contiguous range and gather
+    the tables on rank 0.  ``items`` is any sliceable list (records, profiles or
+    pairs of them), ``lengths`` their lengths."""
+    if rank is None or world is None:
+        rank, world = env_rank_world()
+    lo, hi = partition(lengths, world)[rank]
+    local = scan_fn(items[lo:hi])
+    return gather_frames(local, rank, world, dist)

@@ -161,8 +161,11 @@ def read_pfm_table(path):
     return letters, {l: [float(x) for x in df[l]] for l in letters}
 
 
-def build_pssm(path, pseudocount, background):
+def build_pssm(path, pseudocount, background, alphabet_letters):
+    """counts are taken in alphabet.letters order, the order Biopython's Motif stores
+    them in and sums them in when it normalises (GAUC / EHTBLRM), not file order"""
     letters, counts = read_pfm_table(path)
+    counts = {l: counts[l] for l in alphabet_letters}
     return letters, oracle.log_odds(oracle.normalize(counts, pseudocount), background)
 
 
@@ -248,14 +251,14 @@ def main():
         pwm_cases.append({"name": name, "note": note, "sequence": sequence,
                           "matrix": [f64list(r) for r in M], "scores": f32list(scores)})
 
-    _, pssm0 = build_pssm(slbp_seq, 0.0, None)
+    _, pssm0 = build_pssm(slbp_seq, 0.0, None, "GAUC")
     add_pwm("hist_slbp_pc0_uniform", hist_rna, matrix_acgu(pssm0), "config 1 seq side: -u -C 0")
     bg_hist = oracle.compute_background([hist_rna], "GAUC")
-    _, pssm1 = build_pssm(slbp_seq, 0.01, bg_hist)
+    _, pssm1 = build_pssm(slbp_seq, 0.01, bg_hist, "GAUC")
     add_pwm("hist_slbp_pc001_bg", hist_rna, matrix_acgu(pssm1), "computed background, -C 0.01")
     add_pwm("hist_dna_letters_mixed_case", hist_dna[:120] + hist_dna[120:].lower(), matrix_acgu(pssm0),
             "T/t accepted like U/u, lower case accepted (_pwm.c:47-60)")
-    _, pssm_t = build_pssm(os.path.join(REF, "tests/test_seq_pfm.txt"), 0.0, None)
+    _, pssm_t = build_pssm(os.path.join(REF, "tests/test_seq_pfm.txt"), 0.0, None, "GAUC")
     for rid, s in fasta_records(os.path.join(REF, "tests/test.fa")):
         add_pwm("testfa_%s_test_seq_pfm" % rid, s, matrix_acgu(pssm_t), "tests/ PFM has header order G A U C")
     letters_pool = np.array(list("ACGU"))
@@ -306,8 +309,8 @@ def main():
 
     # ---- (2) _py_calculate -----------------------------------------------------
     css = ContextualSecondaryStructure()
-    _, spssm0 = build_pssm(slbp_struct, 0.0, None)
-    _, spssm1 = build_pssm(slbp_struct, 0.01, None)
+    _, spssm0 = build_pssm(slbp_struct, 0.0, None, "EHTBLRM")
+    _, spssm1 = build_pssm(slbp_struct, 0.01, None, "EHTBLRM")
     py_cases = []
 
     def add_py(name, sequence, pssm, m_override=None):
@@ -366,9 +369,9 @@ def main():
         f.write("PO\t" + "\t".join("BEHLMRT") + "\n")
         for i, row in enumerate(prof):
             f.write(str(i) + "\t" + "\t".join(str(float(x)) for x in row) + "\n")
-    synth_counts = {l: list(rng.dirichlet(np.full(7, 0.5), size=12)[:, k]) for k, l in enumerate("BEHLMRT")}
+    synth_counts = {l: list(rng.dirichlet(np.full(7, 0.5), size=12)[:, k]) for k, l in enumerate("EHTBLRM")}
     zero_mask = rng.random((12, 7)) < 0.15
-    for k, l in enumerate("BEHLMRT"):
+    for k, l in enumerate("EHTBLRM"):
         for i in range(12):
             if zero_mask[i, k]:
                 synth_counts[l][i] = 0.0

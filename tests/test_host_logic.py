@@ -1,0 +1,169 @@
+"""Host-side logic (no GPU): the known answers the reference's own tests hold
+(tests/motif_scan_test.py, tests/preprocess_seq_test.py), PFM -> PSSM, packing."""
+import bz2
+import gzip
+import math
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import DATA_DIR
+from rnascan_amd import fasta, pack, pssm, shard
+
+
+# ---- the reference's own unit tests, restated ---------------------------------
+def test_parse_sequences_reference_fixture():
+    recs = list(fasta.parse_sequences([os.path.join(DATA_DIR, "test.fa")]))
+    assert [r.id for r in recs] == ["read1", "read2"]
+    assert all(r.seq == "UUUUGCUCUGUAUAUA" for r in recs)
+
+
+def test_compute_background_reference_known_answer(golden):
+    g = golden["ref_tests"]["compute_background"]
+    bg = fasta.compute_background([os.path.join(DATA_DIR, g["fasta"])], fasta.RNA, verbose=False)
+    for key, value in g["expected"].items():
+        assert round(abs(bg[key] - value), g["places"]) == 0      # assertAlmostEqual(..., 3)
+    assert bg == {"G": 5 / 36, "A": 7 / 36, "U": 19 / 36, "C": 5 / 36}
+    assert list(bg.keys()) == list("GAUC")
+
+
+def test_preprocess_seq_reference_cases(golden):
+    for c in golden["ref_tests"]["preprocess_seq"]:
+        got = fasta.preprocess_seq(c["seq"], target_is_rna=(c["target"] == "RNA"), source_is_rna=(c["source"] == "RNA"))
+        assert got == c["expected"], c
+
+
+def test_compute_background_matches_oracle_loop(oracle):
+    recs = list(fasta.parse_sequences(os.path.join(DATA_DIR, "HIST2H3C_3p_end.fa")))
+    s = fasta.preprocess_seq(recs[0].seq, True)
+    want = oracle.compute_background([s], "GAUC")
+    got = fasta.compute_background(os.path.join(DATA_DIR, "HIST2H3C_3p_end.fa"), fasta.RNA, verbose=False)
+    assert got == want
+
+
+# ---- FASTA details ---------------------------------------------------------------
+def test_fasta_header_multiline_and_compressed(tmp_path):
+    src = os.path.join(DATA_DIR, "HIST2H3C_3p_end.fa")
+    rec = list(fasta.parse_sequences(src))[0]
+    assert rec.id == "hg19_dna"
+    assert rec.description.startswith("hg19_dna range=chr1:149824452-149824687")
+    assert len(rec.seq) == 236 and set(rec.seq) <= set("ACGT")
+    gz, bz = str(tmp_path / "a.fa.gz"), str(tmp_path / "a.fa.bz2")
+    with open(src, "rb") as f, gzip.open(gz, "wb") as g:
+        shutil.copyfileobj(f, g)
+    with open(src, "rb") as f, bz2.open(bz, "wb") as g:
+        shutil.copyfileobj(f, g)
+    assert list(fasta.parse_sequences([gz, bz])) == [rec, rec]
+
+
+def test_load_background_literal_file(tmp_path):
+    p = tmp_path / "bg.txt"
+    p.write_text("{'A': 0.3, 'C': 0.2, 'G': 0.2, 'U': 0.3}")
+    assert fasta.load_background(str(p), False, None, fasta.RNA)["A"] == 0.3
+    assert fasta.load_background(None, True, None, fasta.RNA) is None
+
+
+def test_read_profile_and_listing(tmp_path):
+    src = os.path.join(DATA_DIR, "HIST2H3C_3p_end_structure.txt")
+    letters, prof = fasta.read_profile(src)
+    assert letters == list("BEHLMRT") and prof.shape == (236, 7)
+    assert prof[0].tolist() == [0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    shutil.copyfile(src, tmp_path / "structure.hg19_dna.txt")
+    shutil.copyfile(src, tmp_path / "structure.a.b.txt")
+    (tmp_path / "other.txt").write_text("x")
+    assert sorted(fasta.list_profiles(str(tmp_path))) == sorted(
+        [("hg19_dna", str(tmp_path / "structure.hg19_dna.txt")), ("a.b", str(tmp_path / "structure.a.b.txt"))])
+
+
+# ---- PFM -> PSSM -------------------------------------------------------------------
+def test_pfm2pssm_matches_oracle_loops_and_golden(oracle, golden):
+    path = os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt")
+    P = pssm.pfm2pssm(path, 0.0, fasta.RNA, None)
+    assert list(P.keys()) == list("GAUC") and P.length == 18
+    raw = pssm.read_pfm(path)
+    counts = {l: raw[l].tolist() for l in "GAUC"}          # alphabet.letters order, as Biopython sums it
+    want = oracle.log_odds(oracle.normalize(counts, 0.0), None)
+    for l in "ACGU":
+        assert P[l].tolist() == want[l]
+    # the operand recorded next to the reference's outputs in the fixture
+    g = golden["calculate_route"]["pssm"]
+    for l in "ACGU":
+        assert P[l].tolist() == g[l]
+    assert P.letter_table("ACGU")[0, :4].tolist() == [1.579627261360602, -1.9358833760604863, -1.1421163018076363, -1.75332079856928]
+    assert np.isnan(P.letter_table("ACGU")[:, 4:]).all()
+
+
+def test_pfm2pssm_struct_inf_cells_and_background():
+    path = os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_struct.txt")
+    P = pssm.pfm2pssm(path, 0.0, fasta.STRUCT, None)
+    M = P.matrix("BEHLMRT")
+    assert np.isneginf(M).sum() == 21 and np.isneginf(M[1]).sum() == 5
+    bg = {l: 1.0 for l in fasta.STRUCT}                                       # unnormalised background is renormalised
+    assert np.array_equal(pssm.pfm2pssm(path, 0.0, fasta.STRUCT, bg).matrix("BEHLMRT"), M)
+    P1 = pssm.pfm2pssm(path, 0.01, fasta.STRUCT, None)
+    assert np.isfinite(P1.matrix("BEHLMRT")).all()
+
+
+def test_log_odds_special_cells():
+    pw = {"A": np.array([0.5, 0.0]), "C": np.array([0.5, 1.0])}
+    lo = pssm.log_odds(pw, {"A": 0.0, "C": 1.0})
+    assert lo["A"][0] == math.inf and math.isnan(lo["A"][1])
+    assert lo["C"].tolist() == [-1.0, 0.0]
+    lo = pssm.log_odds(pw, None)
+    assert lo["A"].tolist() == [0.0, -math.inf]
+
+
+def test_wrong_alphabet_raises_keyerror():
+    with pytest.raises(KeyError):
+        pssm.pfm2pssm(os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt"), 0.0, fasta.STRUCT, None)
+
+
+def test_test_pfm_header_order_is_honoured():
+    """tests/test_seq_pfm.txt has header order G A U C: columns are matched by letter"""
+    P = pssm.pfm2pssm(os.path.join(DATA_DIR, "test_seq_pfm.txt"), 0.0, fasta.RNA, None)
+    raw = pssm.read_pfm(os.path.join(DATA_DIR, "test_seq_pfm.txt"))
+    assert list(raw.keys()) == list("GAUC")
+    row0 = np.array([raw[l][0] for l in "GAUC"])
+    assert np.allclose(P.letter_table("ACGU")[0, :4], np.log2(np.array([raw[l][0] for l in "ACGU"]) / row0.sum() / 0.25))
+
+
+# ---- packing -----------------------------------------------------------------------
+def test_encode_rna_letter_classes():
+    assert pack.encode_rna("ACGUTacgutN-").tolist() == [0, 1, 2, 3, 3, 0, 1, 2, 3, 3, 7, 7]
+    assert pack.encode_letters("EhtBLRMx.", pack.STRUCT_LETTERS).tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 7]
+
+
+def test_pack_layout_and_locate():
+    codes = [np.array([0, 1, 2], np.uint8), np.zeros(0, np.uint8), np.array([3], np.uint8)]
+    profs = [np.full((3, 7), 0.5), np.zeros((0, 7)), np.ones((1, 7))]
+    s = pack.pack(codes, profs)
+    assert s.codes.tolist() == [0, 1, 2, 7, 7, 3, 7]
+    assert s.offsets.tolist() == [0, 4, 5] and s.lengths.tolist() == [3, 0, 1] and s.n_pos == 7
+    assert s.profile.dtype == np.float32 and s.profile.shape == (7, 7)
+    assert s.profile[3].tolist() == [0] * 7 and s.profile[5].tolist() == [1] * 7
+    rec, start = s.locate([0, 2, 5])
+    assert rec.tolist() == [0, 0, 2] and start.tolist() == [0, 2, 0]
+    assert s.n_windows(2) == 2 and s.window_mask(2).tolist() == [True, True, False, False, False, False, False]
+    with pytest.raises(ValueError):
+        pack.pack(codes, [np.zeros((2, 7))] * 3)
+
+
+# ---- sharding ------------------------------------------------------------------------
+def test_partition_contiguous_balanced():
+    L = [3000] * 10
+    assert shard.partition(L, 1) == [(0, 10)]
+    assert shard.partition(L, 2) == [(0, 5), (5, 10)]
+    parts = shard.partition([10, 10, 10, 1000, 10, 10], 3)
+    assert parts[0][0] == 0 and parts[-1][1] == 6
+    assert all(parts[i][1] == parts[i + 1][0] for i in range(2))
+    assert shard.partition([], 4) == [(0, 0)] * 4
+    assert shard.partition([5], 3)[-1][1] == 1
+    rng = np.random.default_rng(0)
+    L = rng.integers(1, 5000, size=1000)
+    for w in (2, 4, 8):
+        parts = shard.partition(L, w)
+        loads = [int((L[a:b] + 1).sum()) for a, b in parts]
+        assert sum(loads) == int((L + 1).sum())
+        assert max(loads) - min(loads) <= 2 * 5001

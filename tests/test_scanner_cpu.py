@@ -1,0 +1,168 @@
+"""Table layer and CLI on a GPU-less host.  Scores come from the TEST-ONLY
+OracleEngine (tests/engines.py); what is checked here is the host logic: record
+packing, thresholds, 1-based coordinates, rounding, column order, the fused
+combined scan against the reference's own combine() output."""
+import io
+import os
+import shutil
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import DATA_DIR
+from engines import OracleEngine
+from rnascan_amd import cli, fasta, pack, pssm, scanner
+
+SEQ_PFM = os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt")
+STRUCT_PFM = os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_struct.txt")
+HIST_FA = os.path.join(DATA_DIR, "HIST2H3C_3p_end.fa")
+HIST_PROFILE = os.path.join(DATA_DIR, "HIST2H3C_3p_end_structure.txt")
+
+
+@pytest.fixture()
+def avgdir(tmp_path):
+    d = tmp_path / "avg"
+    d.mkdir()
+    shutil.copyfile(HIST_PROFILE, d / "structure.hg19_dna.txt")
+    return str(d)
+
+
+def hist_bg():
+    rec = list(fasta.parse_sequences(HIST_FA))[0]
+    return {l: c for l, c in fasta.compute_background(HIST_FA, fasta.RNA, verbose=False).items()}, rec
+
+
+def test_scan_records_matches_reference_seq_table(golden):
+    bg, rec = hist_bg()
+    P = {"SLBP_seq": pssm.pfm2pssm(SEQ_PFM, 0.01, fasta.RNA, bg)}
+    df = scanner.scan_records(OracleEngine(), [rec], P, fasta.RNA, 0.0)
+    want = golden["combine"]["seq_rows"]
+    assert list(df.columns) == ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds"]
+    assert df["LogOdds"].dtype == np.float32 == np.dtype(golden["combine"]["seq_logodds_dtype"])
+    got = [[r[0], r[1], r[2], int(r[3]), int(r[4]), r[5], float(r[6])] for r in df.itertuples(index=False)]
+    assert got == want
+
+
+def test_scan_profile_dir_matches_reference_scan_main(golden, avgdir):
+    P = {"SLBP_struct": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    df = scanner.scan_profile_dir(OracleEngine(), avgdir, P, 0.0, "aligned", np.float64)
+    g = golden["scan_main_dir"]
+    assert list(df.columns) == g["columns"]
+    got = [[r[0], r[1], r[2], int(r[3]), int(r[4]), r[5], float(r[6])] for r in df.itertuples(index=False)]
+    assert len(got) == len(g["rows"])
+    for a, b in zip(got, g["rows"]):
+        assert a[:6] == b[:6] and abs(a[6] - b[6]) <= 1e-9
+
+
+def assert_tsv_equal(got, want, float_cols=("LogOdds.Struct", "LogOdds.SeqStruct"), tol=1e-9):
+    """every field identical as TEXT except the unrounded fp64 structure columns, which the
+    reference computes through BLAS ddot (summation order unspecified): those within tol"""
+    g, w = [l.split("\t") for l in got.splitlines()], [l.split("\t") for l in want.splitlines()]
+    assert g[0] == w[0]
+    assert len(g) == len(w)
+    fc = [g[0].index(c) for c in float_cols if c in g[0]]
+    for a, b in zip(g[1:], w[1:]):
+        assert len(a) == len(b)
+        for k, (x, y) in enumerate(zip(a, b)):
+            if k in fc:
+                assert abs(float(x) - float(y)) <= tol, (x, y)
+            else:
+                assert x == y, (g[0][k], x, y)
+
+
+def test_combined_tsv_matches_reference_output(golden, avgdir):
+    """rnascan -p SEQ -q STRUCT -C 0.01 -m 0 -B <uniform> fasta avgdir: the TSV the
+    reference's scan_main + combine + _add_match_id + to_csv produced"""
+    out = io.StringIO()
+    argv = ["-p", SEQ_PFM, "-q", STRUCT_PFM, "-C", "0.01", "-m", "0", HIST_FA, avgdir]
+    # sequence background computed from the FASTA (as make_golden did); structure side
+    # needs a uniform background file because -u would also make the sequence side uniform
+    bgfile = os.path.join(os.path.dirname(avgdir), "bg_struct.txt")
+    open(bgfile, "w").write(repr({l: 1.0 / 7 for l in fasta.STRUCT}))
+    os.symlink(SEQ_PFM, os.path.join(os.path.dirname(avgdir), "SLBP_seq.txt"))
+    os.symlink(STRUCT_PFM, os.path.join(os.path.dirname(avgdir), "SLBP_struct.txt"))
+    argv[1] = os.path.join(os.path.dirname(avgdir), "SLBP_seq.txt")
+    argv[3] = os.path.join(os.path.dirname(avgdir), "SLBP_struct.txt")
+    cli.main(argv + ["-B", bgfile], engine=OracleEngine(), out=out)
+    assert_tsv_equal(out.getvalue(), golden["combine"]["tsv"])
+
+
+def test_fused_combined_equals_two_tables_plus_join(avgdir):
+    bg, rec = hist_bg()
+    eng = OracleEngine()
+    sp = {"s": pssm.pfm2pssm(SEQ_PFM, 0.01, fasta.RNA, bg)}
+    tp = {"t": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    named = scanner.load_profile_dir(avgdir)
+    for thr in (-np.inf, -5.0, 0.0, 6.0):
+        fused = scanner.scan_combined(eng, [rec], named, sp, tp, thr, "aligned", np.float64)
+        a = scanner.scan_records(eng, [rec], sp, fasta.RNA, thr)
+        b = scanner.scan_profiles(eng, named, tp, thr, "aligned", np.float64)
+        joined = scanner.combine(a, b)
+        assert list(fused.columns) == list(joined.columns)
+        pd.testing.assert_frame_equal(fused.reset_index(drop=True), joined.reset_index(drop=True), check_dtype=False)
+
+
+def test_fused_combined_declines_unpairable_inputs(avgdir):
+    bg, rec = hist_bg()
+    sp = {"s": pssm.pfm2pssm(SEQ_PFM, 0.01, fasta.RNA, bg)}
+    tp = {"t": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    named = scanner.load_profile_dir(avgdir)
+    short = fasta.Record(rec.id, rec.description, rec.seq[:100])
+    assert scanner.scan_combined(OracleEngine(), [short], named, sp, tp, 0.0) is None
+    assert scanner.scan_combined(OracleEngine(), [rec, rec], named, sp, tp, 0.0) is None
+    other = fasta.Record("nobody", "nobody", rec.seq)
+    assert len(scanner.scan_combined(OracleEngine(), [other], named, sp, tp, 0.0)) == 0
+
+
+def test_pairing_switch_reproduces_both_reference_behaviours(golden):
+    cases = {c["name"]: c for c in golden["scan_averaged_structure"]}
+    P = {"m": pssm.pfm2pssm(STRUCT_PFM, 0.0, fasta.STRUCT, None)}
+    for pairing, name in (("positional", "hist_slbp_pc0_positional"), ("aligned", "hist_slbp_pc0_aligned")):
+        df = scanner.scan_averaged_structure(OracleEngine(), HIST_PROFILE, P, -np.inf, pairing)
+        want = cases[name]["rows"]
+        assert df["Start"].tolist() == [r[0] for r in want] and df["End"].tolist() == [r[1] for r in want]
+        assert np.allclose(df["LogOdds"].to_numpy(), [r[2] for r in want], rtol=0, atol=1e-9)
+        assert list(df.columns) == cases[name]["columns"] and (df["Sequence"] == ".").all()
+
+
+def test_minus_inf_threshold_drops_nan_and_minus_inf_windows():
+    rec = fasta.Record("r", "r", "ACGUNACGUACGUACGU")
+    T = {"m": pssm.PSSM("GAUC", {"A": [0.5, -np.inf], "C": [0.1, 0.2], "G": [0.3, 0.1], "U": [-0.2, 0.4]})}
+    df = scanner.scan_records(OracleEngine(), [rec], T, fasta.RNA, float("-inf"))
+    starts = df["Start"].tolist()
+    assert 4 not in starts and 5 not in starts          # windows covering N
+    for s in starts:                                     # second letter A gives -inf: dropped
+        assert rec.seq[s] != "A"
+    assert len(starts) > 0
+
+
+def test_struct_letter_string_mode_rounds_like_python():
+    P = {"m": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    rec = fasta.Record("s", "s", "EEEEEEEELLLLHHHHHHLLLLRRRREEEEEEEEEEEEE")
+    df = scanner.scan_records(OracleEngine(), [rec], P, fasta.STRUCT, -1000.0)
+    assert df["LogOdds"].dtype == np.float64 and len(df) == len(rec.seq) - 18 + 1
+    assert all(round(x, 3) == x for x in df["LogOdds"])
+    assert df["Sequence"].iloc[0] == rec.seq[:18]
+
+
+def test_cli_modes_and_errors(tmp_path, capsys):
+    with pytest.raises(SystemExit):
+        cli.main([HIST_FA], engine=OracleEngine())                      # no PFM
+    with pytest.raises(SystemExit):
+        cli.main(["-p", SEQ_PFM, "-u", "-b", "x", HIST_FA], engine=OracleEngine())
+    with pytest.raises(SystemExit):
+        cli.main(["-p", SEQ_PFM, "-q", STRUCT_PFM, HIST_FA], engine=OracleEngine())   # two PFMs, one file
+    out = io.StringIO()
+    cli.main(["-p", SEQ_PFM, "-u", "-m", "8", HIST_FA], engine=OracleEngine(), out=out)
+    lines = out.getvalue().splitlines()
+    assert lines[0].split("\t") == ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds", "Match_ID"]
+    assert len(lines) == 2 and lines[1].split("\t")[3:8] == ["213", "230", "AAAGGCUCUUUUCAGAGC", "14.259", "1"]
+    out = io.StringIO()
+    cli.main(["-p", SEQ_PFM, "-t", "AAAGGCTCTTTTCAGAGCaa", "-m", "3"], engine=OracleEngine(), out=out)
+    row = out.getvalue().splitlines()[1].split("\t")
+    assert row[0] == "testseq" and row[3:7] == ["1", "18", "AAAGGCUCUUUUCAGAGC", "14.259"]
+    with pytest.raises(SystemExit):
+        cli.main(["-p", SEQ_PFM, "-g", HIST_FA], engine=OracleEngine(), out=io.StringIO())   # --bgonly prints and exits
+    err = capsys.readouterr().err
+    assert "Loading PFM" in err and "Found 1 motifs" in err and "Scanning sequences" in err and "Processed 1 sequences" in err

@@ -1,0 +1,101 @@
+"""N>1 path on CPU: two gloo ranks each scan their contiguous record range (scores from
+the TEST-ONLY OracleEngine), rank 0 gathers; the result must equal the unsharded table."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import DATA_DIR, REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_inputs():
+    from rnascan_amd import fasta, pssm
+    rng = np.random.default_rng(42)
+    recs = []
+    for i in range(37):
+        L = int(rng.integers(0, 400))
+        recs.append(fasta.Record("r%d" % i, "r%d some description" % i, "".join(rng.choice(list("ACGTN"), size=L, p=[.24, .24, .24, .24, .04]))))
+    P = {"SLBP": pssm.pfm2pssm(os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt"), 0.01, fasta.RNA, None)}
+    return recs, P
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from engines import OracleEngine
+    from rnascan_amd import fasta, scanner, shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    recs, P = _make_inputs()
+    eng = OracleEngine()
+    table = shard.scan_sharded(recs, [len(r.seq) for r in recs],
+                               lambda part: scanner.scan_records(eng, part, P, fasta.RNA, -2.0),
+                               rank=rank, world=world, dist=dist)
+    if rank == 0:
+        scanner._add_match_id(table)
+        table.to_csv(os.path.join(outdir, "sharded.tsv"), sep="\t", index=False)
+    else:
+        assert table is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_scan_equals_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    from engines import OracleEngine
+    from rnascan_amd import fasta, scanner
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    recs, P = _make_inputs()
+    single = scanner.scan_records(OracleEngine(), recs, P, fasta.RNA, -2.0)
+    scanner._add_match_id(single)
+    want = single.to_csv(sep="\t", index=False)
+    got = open(tmp_path / "sharded.tsv").read()
+    assert len(single) > 20
+    assert got == want
+
+
+def _cli_worker(rank, world, port, outdir, argv):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RNASCAN_DIST_BACKEND": "gloo"})
+    from engines import OracleEngine
+    from rnascan_amd import cli
+    with open(os.path.join(outdir, "out.%d.tsv" % rank), "w") as out:
+        cli.main(argv, engine=OracleEngine(), out=out)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_cli_under_two_gloo_ranks(tmp_path):
+    """the drop-in CLI launched torchrun-style: rank 0 prints the whole table, rank 1 nothing"""
+    import io
+    import torch.multiprocessing as mp
+    from engines import OracleEngine
+    from rnascan_amd import cli
+    rng = np.random.default_rng(7)
+    fa = tmp_path / "many.fa"
+    with open(fa, "w") as f:
+        for i in range(23):
+            f.write(">rec%d desc %d\n%s\n" % (i, i, "".join(rng.choice(list("ACGT"), size=int(rng.integers(30, 500))))))
+    argv = ["-p", os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-m", "-1", str(fa)]
+    mp.spawn(_cli_worker, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    single = io.StringIO()
+    cli.main(argv, engine=OracleEngine(), out=single)
+    assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
+    assert open(tmp_path / "out.1.tsv").read() == ""
+    assert single.getvalue().count("\n") > 10
