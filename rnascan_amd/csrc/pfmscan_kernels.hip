@@ -177,8 +177,8 @@ template <int V, typename PROF_T>
 struct ProfileLayout {
     static constexpr int TILE = V * BLOCK;
     // both regions are whole 1-KiB LDS-DMA pieces (one wave-instruction = 64 x 16 B)
-    __host__ __device__ static constexpr int prof_bytes(int m) { return round_up((TILE + m - 1) * 7 * (int)sizeof(PROF_T), 1024); }
-    __host__ __device__ static constexpr int code_bytes(int m) { return round_up(TILE + m - 1, 1024); }
+    __host__ __device__ static constexpr int prof_bytes(int m) { return round_up((TILE + m) * 7 * (int)sizeof(PROF_T), 1024); }   // +1 row: the slide-in is unconditional
+    __host__ __device__ static constexpr int code_bytes(int m) { return round_up(TILE + m, 1024); }
     __host__ __device__ static int buf_bytes(int m, bool has_seq) { return prof_bytes(m) + (has_seq ? code_bytes(m) : 0); }
     __host__ __device__ static int total(int m, bool has_seq, int nbuf)
     {
@@ -306,13 +306,13 @@ __device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsig
                                              double (&acc_sq)[V])
 {
     double rows[V][7];
-    uint32_t cofs[V];
+    uint32_t sadr[V];                // LDS byte offset of this slot's letter in table row j0 (advanced per j0 round)
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         const PROF_T *r = prof_lds + (la + s) * 7;
 #pragma unroll
         for (int k = 0; k < 7; ++k) rows[s][k] = (double)r[k];
-        cofs[s] = HAS_SEQ ? (((uint32_t)code_lds[la + s] & 7u) << 3) : 0u;
+        sadr[s] = HAS_SEQ ? (((uint32_t)code_lds[la + s] & 7u) << 3) : 0u;
         acc_st[s] = 0.0;
         acc_sq[s] = 0.0;
     }
@@ -322,10 +322,14 @@ __device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsig
         for (int u = 0; u < V; ++u) {
             const int j = j0 + u;
             if (j < m) {                          // wave-uniform
+                // constant address space: the table is read-only for the whole launch, so the
+                // row is fetched with s_load (SGPR operands of v_fmac_f64) even in kernels that
+                // also store to global memory
+                const __attribute__((address_space(4))) double *prow =
+                    (const __attribute__((address_space(4))) double *)(pssm + j * 7);
                 double P[7];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) P[k] = pssm[j * 7 + k];
-                const char *trow = tseq_lds + j * 64;
+                for (int k = 0; k < 7; ++k) P[k] = prow[k];
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     const int slot = (u + v) % V;  // holds stream position la + v + j
@@ -343,15 +347,19 @@ __device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsig
                         for (int k = 1; k < 7; ++k) d = fma(rows[slot][k], P[k], d);
                         acc_st[v] += nan_to_num(d);
                     }
-                    if (HAS_SEQ) acc_sq[v] += *reinterpret_cast<const double *>(trow + cofs[slot]);
+                    // table row j = j0 + u: the j0 part lives in sadr, u * 64 is an immediate offset
+                    if (HAS_SEQ) acc_sq[v] += *reinterpret_cast<const double *>(tseq_lds + sadr[slot] + u * 64);
                 }
-                if (j + 1 < m) {                  // slot u is dead now: slide in position la + j + V
-                    const PROF_T *r = prof_lds + (la + j + V) * 7;
+                // slot u is dead now: slide in position la + j + V (always staged: tile holds TILE + m rows)
+                const PROF_T *r = prof_lds + (la + j + V) * 7;
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) rows[u][k] = (double)r[k];
-                    if (HAS_SEQ) cofs[u] = ((uint32_t)code_lds[la + j + V] & 7u) << 3;
-                }
+                for (int k = 0; k < 7; ++k) rows[u][k] = (double)r[k];
+                if (HAS_SEQ) sadr[u] = ((((uint32_t)code_lds[la + j + V]) & 7u) << 3) + (uint32_t)j0 * 64u;
             }
+        }
+        if (HAS_SEQ) {
+#pragma unroll
+            for (int s = 0; s < V; ++s) sadr[s] += V * 64;
         }
     }
     if (FINITE) {
@@ -420,6 +428,67 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, int64_t tile0, int 
     }
 }
 
+// Output path without workgroup barriers: wave w stages its 64*V scores in the part of
+// the tile buffer only IT reads -- rows [w*64V + m-1, (w+1)*64V): the first m-1 rows of its
+// band are also the previous wave's halo and are left alone -- and copies them out itself
+// as 16-byte stores.  LDS operations of one wave execute in order, so a wave-level fence
+// is all the synchronisation needed.
+template <int V, bool HAS_SEQ, typename PROF_T>
+__device__ __forceinline__ void emit_tile_wave(const ScanArgs &a, int64_t tile0, int la, double (&acc_st)[V],
+                                               double (&acc_sq)[V], unsigned char *tile_buf)
+{
+    constexpr int WN = 64 * V;                      // windows per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_pos = a.n_pos;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
+    const int start = ((wave * WN + a.m - 1) * 7 * (int)sizeof(PROF_T) + 15) & ~15;
+    double *sto = reinterpret_cast<double *>(tile_buf + start);
+    float *so = reinterpret_cast<float *>(tile_buf + start + WN * 8);
+    const int lw = lane * V;                        // first window of this lane inside the wave's band
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        sto[lw + v] = acc_st[v];
+        if (HAS_SEQ) so[lw + v] = (float)acc_sq[v];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t w0 = tile0 + (int64_t)wave * WN;  // first window of the wave's band
+    if (HAS_SEQ && a.out_seq) {
+#pragma unroll
+        for (int c0 = 0; c0 < WN / 4; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < WN / 4) {
+                const int64_t p = w0 + 4 * (int64_t)c;
+                if (p + 4 <= n_pos) {
+                    __builtin_nontemporal_store(reinterpret_cast<const f32x4 *>(so)[c], reinterpret_cast<f32x4 *>(a.out_seq + p));
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (p + e < n_pos) a.out_seq[p + e] = so[4 * c + e];
+                }
+            }
+        }
+    }
+    if (a.out_struct) {
+#pragma unroll
+        for (int c0 = 0; c0 < WN / 2; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < WN / 2) {
+                const int64_t p = w0 + 2 * (int64_t)c;
+                if (p + 2 <= n_pos) {
+                    __builtin_nontemporal_store(reinterpret_cast<const f64x2 *>(sto)[c], reinterpret_cast<f64x2 *>(a.out_struct + p));
+                } else if (p < n_pos) {
+                    a.out_struct[p] = sto[2 * c];
+                }
+            }
+        }
+    }
+}
+
 // one tile per workgroup; overlap comes from several resident workgroups per CU
 // launch bound = the residency the LDS tile allows (4 workgroups/CU at V=5, 3 at V=7)
 template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, int DMA>
@@ -455,7 +524,10 @@ __global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_prof
         if (keep == 1.2345e300) a.out_struct[0] = keep;
         return;
     }
-    emit_tile<V, HAS_SEQ, HITS>(a, tile0, la, acc_st, acc_sq, smem);
+    if (HITS || (a.ablate & 8))
+        emit_tile<V, HAS_SEQ, HITS>(a, tile0, la, acc_st, acc_sq, smem);
+    else
+        emit_tile_wave<V, HAS_SEQ, PROF_T>(a, tile0, la, acc_st, acc_sq, smem);
 }
 
 // Persistent, double-buffered form: a workgroup walks tiles b, b+G, b+2G, ...
@@ -488,6 +560,84 @@ __global__ __launch_bounds__(BLOCK) void k_profile_pipe(const ScanArgs a, const 
                                                  a.struct_pssm, m, la, acc_st, acc_sq);
         emit_tile<V, HAS_SEQ, HITS>(a, (int64_t)t * L::TILE, la, acc_st, acc_sq, buf);
         cur ^= 1;
+    }
+}
+
+// Persistent, register-prefetched form ("issue early / write late"): a workgroup
+// walks tiles b, b+G, ...; at the top of an iteration every thread issues ALL of its
+// 16-byte loads of the NEXT tile into registers, scores the current tile out of LDS
+// while those loads are in flight, then (after the outputs left through the same LDS
+// buffer) writes the registers into LDS.  One LDS buffer per workgroup, so residency
+// stays at 3 workgroups / 12 waves per CU, and every workgroup has a whole tile
+// outstanding towards HBM for the whole scoring phase.
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
+__global__ __launch_bounds__(BLOCK, 3) void k_profile_stream(const ScanArgs a, const int n_tiles)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    constexpr int MAXCH = (L::prof_bytes(PFMSCAN_MAX_M) / 16 + BLOCK - 1) / BLOCK;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int m = a.m;
+    const int tid = threadIdx.x;
+    const int64_t n_pos = a.n_pos;
+    const int prof_bytes = L::prof_bytes(m);
+    const int code_bytes = L::code_bytes(m);
+    const int nch = prof_bytes >> 4, ncc = code_bytes >> 4;
+    const int64_t total_bytes = n_pos * 7 * (int64_t)sizeof(PROF_T);
+    char *tseq_lds = reinterpret_cast<char *>(smem + L::buf_bytes(m, HAS_SEQ));
+    if (HAS_SEQ)
+        for (int i = tid; i < m * 8; i += BLOCK) reinterpret_cast<double *>(tseq_lds)[i] = a.letter_table[i];
+    const int la = tid * V;
+
+    auto interior = [&](int t) -> bool {
+        const int64_t tile0 = (int64_t)t * L::TILE;
+        const int64_t g0 = tile0 * 7 * (int64_t)sizeof(PROF_T);
+        return (g0 + prof_bytes <= total_bytes) && (!HAS_SEQ || tile0 + code_bytes <= n_pos);
+    };
+
+    int t = blockIdx.x;
+    if (t < n_tiles) stage_tile<V, HAS_SEQ, PROF_T, 0>(a, (int64_t)t * L::TILE, smem, m);
+    __syncthreads();
+#pragma unroll 1
+    for (; t < n_tiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const bool have_next = tn < n_tiles;
+        const bool pre = have_next && interior(tn);          // workgroup-uniform
+        u32x4 r[MAXCH];
+        u32x4 rc = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) r[i] = rc;           // defined on both paths: keeps r[] out of scratch
+        if (pre) {
+            const int64_t tile0n = (int64_t)tn * L::TILE;
+            const u32x4 *gsrc = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(a.profile) +
+                                                                tile0n * 7 * (int64_t)sizeof(PROF_T));
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {                 // unconditional, index clamped: keeps r[] in registers
+                const int c = tid + i * BLOCK;
+                r[i] = __builtin_nontemporal_load(gsrc + (c < nch ? c : nch - 1));
+            }
+            if (HAS_SEQ) rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.codes + tile0n) + (tid < ncc ? tid : ncc - 1));
+        }
+        double acc_st[V], acc_sq[V];
+        // opaque copy of the lane's window base: stops hipcc from hoisting the per-lane LDS
+        // addresses of the scoring loop out of the tile loop (they would stay live across the
+        // staging code and push the kernel over the 168-VGPR budget of 3 waves/SIMD)
+        int la_i = la;
+        asm volatile("" : "+v"(la_i));
+        compute_tile<V, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(smem), smem + prof_bytes, tseq_lds,
+                                                 a.struct_pssm, m, la_i, acc_st, acc_sq);
+        emit_tile<V, HAS_SEQ, HITS>(a, (int64_t)t * L::TILE, la_i, acc_st, acc_sq, smem);
+        __syncthreads();                                      // tile (and the output staging) fully consumed
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {
+                const int c = tid + i * BLOCK;
+                if (c < nch) reinterpret_cast<u32x4 *>(smem)[c] = r[i];
+            }
+            if (HAS_SEQ && tid < ncc) reinterpret_cast<u32x4 *>(smem + prof_bytes)[tid] = rc;
+        } else if (have_next) {
+            stage_tile<V, HAS_SEQ, PROF_T, 0>(a, (int64_t)tn * L::TILE, smem, m);
+        }
+        __syncthreads();
     }
 }
 
@@ -563,6 +713,48 @@ static hipError_t launch_pipe_inst(const ScanArgs &a, const Tuning &t, hipStream
     return hipGetLastError();
 }
 
+template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
+static hipError_t launch_stream_inst(const ScanArgs &a, const Tuning &t, hipStream_t stream)
+{
+    using L = ProfileLayout<V, PROF_T>;
+    const int64_t n_tiles = (a.n_pos + L::TILE - 1) / L::TILE;
+    const int lds = L::total(a.m, HAS_SEQ, 1);
+    auto kern = k_profile_stream<V, HAS_SEQ, PROF_T, FINITE, HITS>;
+    static int per_cu = 0;
+    static int per_cu_lds = -1;
+    if (per_cu_lds != lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, (size_t)lds);
+        if (e != hipSuccess) return e;
+        if (nb < 1) return hipErrorInvalidConfiguration;
+        per_cu = nb;
+        per_cu_lds = lds;
+    }
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int bpc = per_cu;
+    if (t.blocks_per_cu > 0 && t.blocks_per_cu < bpc) bpc = t.blocks_per_cu;
+    int64_t grid = (int64_t)n_cu * bpc;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, a, (int)n_tiles);
+    return hipGetLastError();
+}
+
+template <int V, bool HAS_SEQ, typename PROF_T>
+static hipError_t launch_stream_v(const ScanArgs &a, const Tuning &t, hipStream_t stream)
+{
+    if (a.hits) {
+        if (a.struct_finite) return launch_stream_inst<V, HAS_SEQ, PROF_T, true, true>(a, t, stream);
+        return launch_stream_inst<V, HAS_SEQ, PROF_T, false, true>(a, t, stream);
+    }
+    if (a.struct_finite) return launch_stream_inst<V, HAS_SEQ, PROF_T, true, false>(a, t, stream);
+    return launch_stream_inst<V, HAS_SEQ, PROF_T, false, false>(a, t, stream);
+}
+
 template <int V, bool HAS_SEQ, typename PROF_T, int DMA>
 static hipError_t launch_profile_v(const ScanArgs &a, hipStream_t stream)
 {
@@ -588,6 +780,7 @@ static hipError_t launch_pipe_v(const ScanArgs &a, const Tuning &t, hipStream_t 
 template <bool HAS_SEQ, typename PROF_T>
 static hipError_t launch_profile_t(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
+    if (t.pipe == 2) return launch_stream_v<5, HAS_SEQ, PROF_T>(a, t, stream);
     if (t.pipe) {
         if (t.v == 3) return launch_pipe_v<3, HAS_SEQ, PROF_T>(a, t, stream);
         if (t.v == 7) return launch_pipe_v<7, HAS_SEQ, PROF_T>(a, t, stream);
