@@ -212,7 +212,7 @@ __device__ __forceinline__ double struct_window_slow(const PROF_T *prof_lds, int
 // `lds_base` must be wave-uniform: the hardware writes LDS[m0 + 16 * lane].
 __device__ __forceinline__ void dma_issue16(const void *gptr, uint32_t lds_base)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
                  :
                  : "v"(gptr), "s"(lds_base)
                  : "memory");   // m0 is a reserved register: hipcc re-materialises it before each of its own uses
