@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--width", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
+                    help="c3: seq+struct w=12 (the headline metric); c2: sequence-only PFM (BASELINE configs[1], use --width 8)")
     ap.add_argument("--mode", choices=["scores", "hits"], default="scores",
                     help="scores: all-scores (the headline, 41.1 B/window); hits: thresholded hits (29.1 B/window + 20 B/hit)")
     ap.add_argument("--minscore", type=float, default=6.0, help="threshold of --mode hits (seq > m and struct > m)")
@@ -105,7 +107,8 @@ def main():
 
     ctx = _lib.Context(local_rank)
     table, spssm = make_pssms(args.width)
-    motif = ctx.motif(table, spssm)
+    seq_only = args.workload == "c2"
+    motif = ctx.motif(table, None if seq_only else spssm)
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank)
     # zero-filled (touched) outputs: first-touch of fresh device pages would otherwise
     # land in the first kernel launches and skew the per-kernel average rocprof reports
@@ -130,9 +133,12 @@ def main():
     def step():
         if args.mode == "hits":
             hit_count.zero_()
-            ctx.hits_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, args.minscore,
+            ctx.hits_dev(motif, codes.data_ptr(), None if seq_only else profile.data_ptr(),
+                         _lib.PROFILE_NONE if seq_only else _lib.PROFILE_F32, n_pos, args.minscore,
                          args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
                          hit_count.data_ptr(), stream)
+        elif seq_only:
+            ctx.scan_dev(motif, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, out_seq.data_ptr(), None, stream)
         else:
             ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos,
                          out_seq.data_ptr(), out_st.data_ptr(), stream)
@@ -165,15 +171,16 @@ def main():
     result = None
     if rank == 0:
         total_windows = windows * world * args.steps
-        alg_bytes = args.records * args.length * 29 + windows * 12      # per launch, per GPU
+        in_b, out_b, hit_b = (1, 4, 12) if seq_only else (29, 12, 20)
+        alg_bytes = args.records * args.length * in_b + windows * out_b      # per launch, per GPU
         n_hits = None
         if args.mode == "hits":
             n_hits = int(hit_count.item())
-            alg_bytes = args.records * args.length * 29 + min(n_hits, cap) * 20
+            alg_bytes = args.records * args.length * in_b + min(n_hits, cap) * hit_b
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and args.mode == "scores":
+        if os.path.exists(tfile) and args.mode == "scores" and not seq_only:
             try:
                 tj = json.load(open(tfile))
                 if tj.get("records") == args.records and tj.get("length") == args.length and tj.get("width") == args.width:
@@ -181,7 +188,7 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "scored windows/sec (seq+struct, w=%d)" % args.width,
+            "metric": "scored windows/sec (%s, w=%d)" % ("seq-only" if seq_only else "seq+struct", args.width),
             "value": total_windows / elapsed,
             "unit": "windows/s",
             "n_gpus": world,
@@ -194,9 +201,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C3: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, "
-                            "uint8 codes + float32 [n][7] profile, all-scores (f32 seq + f64 struct per window)"
-                            % (args.records, args.length, args.width),
+                "workload": ("C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes"
+                             % (args.records, args.length, args.width)) if seq_only else
+                            ("C3: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, "
+                             "uint8 codes + float32 [n][7] profile, all-scores (f32 seq + f64 struct per window)"
+                             % (args.records, args.length, args.width)),
                 "records_per_gpu": args.records, "record_length": args.length, "pfm_width": args.width,
                 "windows_per_gpu_per_step": windows, "mode": "all-scores" if args.mode == "scores" else "hits",
                 "minscore": None if args.mode == "scores" else args.minscore, "hits_per_step": n_hits,
@@ -205,12 +214,12 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_profile", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": "k_letters" if seq_only else "k_profile", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
 
-        if world == 1 and not args.no_cpu_baseline and args.mode == "scores":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
             from oracle import oracle
             oracle.build()
             stride = args.length + 1

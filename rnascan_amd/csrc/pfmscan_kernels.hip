@@ -70,25 +70,55 @@ __device__ __forceinline__ uint32_t load_codes4(const uint8_t *__restrict__ code
     return w;
 }
 
-// Append hits of one wave-wide predicate: one atomic per wave-instruction that
-// has any hit (hits are rare at real thresholds, so most ballots are empty).
-__device__ __forceinline__ void emit_hits(bool pass, int64_t p, float sq, double st, const ScanArgs &a)
+// Append the hits of one workgroup: every thread brings N windows.  Counts are
+// scanned inside the wave (shuffles) and across the 4 waves (LDS), then ONE returning
+// atomic per workgroup reserves the slots -- and none at all when the workgroup has no
+// hit, the usual case at real thresholds.  (One atomic per wave-instruction saturated
+// the counter word at percent-level hit rates: 9 ms on C2.)  Must be called by all 256
+// threads of the workgroup.  Hits of a workgroup land in position order; workgroups land
+// in arrival order (the host sorts).
+template <int N>
+__device__ __forceinline__ void emit_hits_block(const bool (&pass)[N], const int64_t (&pos)[N], const float (&sq)[N],
+                                                const double (&st)[N], const ScanArgs &a)
 {
-    unsigned long long mask = __ballot(pass);
-    if (mask == 0) return;
-    const int lane = __lane_id();
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(a.hit_count, (unsigned long long)__popcll(mask));
-    base = __shfl(base, leader);
-    if (pass) {
-        unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-        if ((int64_t)slot < a.capacity) {
-            a.hit_pos[slot] = p;
-            if (a.hit_seq) a.hit_seq[slot] = sq;
-            if (a.hit_struct) a.hit_struct[slot] = st;
+    __shared__ unsigned long long hb_base;
+    __shared__ int hb_wave[BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) cnt += pass[i] ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) hb_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            const int t = hb_wave[w];
+            hb_wave[w] = run;
+            run += t;
+        }
+        hb_base = run ? atomicAdd(a.hit_count, (unsigned long long)run) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long slot = hb_base + (unsigned long long)(hb_wave[wave] + incl - cnt);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (pass[i]) {
+            if ((int64_t)slot < a.capacity) {
+                a.hit_pos[slot] = pos[i];
+                if (a.hit_seq) a.hit_seq[slot] = sq[i];
+                if (a.hit_struct) a.hit_struct[slot] = st[i];
+            }
+            ++slot;
         }
     }
+    __syncthreads();                                   // hb_* may be reused by the next call
 }
 
 // ---------------------------------------------------------------------------
@@ -109,10 +139,24 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
     const int ndneed = (m + 2) >> 2;           // highest dword index touched
     OUT_T *__restrict__ out = reinterpret_cast<OUT_T *>(sizeof(OUT_T) == 4 ? (void *)a.out_seq : (void *)a.out_letters_f64);
 
-#pragma unroll 1
+    bool hpass[4 * LET_ITERS];
+    int64_t hpos[4 * LET_ITERS];
+    float hsq[4 * LET_ITERS];
+    double hst[4 * LET_ITERS];
+#pragma unroll
     for (int it = 0; it < LET_ITERS; ++it) {
         const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
-        if (p0 >= n_pos) break;
+        const bool live = p0 < n_pos;
+        if (HITS) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                hpass[4 * it + v] = false;
+                hpos[4 * it + v] = p0 + v;
+                hsq[4 * it + v] = 0.f;
+                hst[4 * it + v] = 0.0;
+            }
+        }
+        if (!live) continue;
         uint32_t w[NDW];
 #pragma unroll
         for (int d = 0; d < NDW; ++d) {
@@ -143,14 +187,15 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
             for (int v = 0; v < 4; ++v) {
                 const float sq = (float)acc[v];
                 const double cmp = sizeof(OUT_T) == 4 ? (double)sq : acc[v];
-                const bool pass = (p0 + v < n_pos) && (cmp > a.thr_seq);
-                emit_hits(pass, p0 + v, sq, acc[v], a);
+                hpass[4 * it + v] = (p0 + v < n_pos) && (cmp > a.thr_seq);
+                hsq[4 * it + v] = sq;
+                hst[4 * it + v] = acc[v];
             }
         } else if (sizeof(OUT_T) == 4) {
             float *o = reinterpret_cast<float *>(out) + p0;
             if (p0 + 4 <= n_pos) {
-                float4 r = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
-                *reinterpret_cast<float4 *>(o) = r;
+                f32x4 r = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(o));
             } else {
                 for (int v = 0; v < 4; ++v)
                     if (p0 + v < n_pos) o[v] = (float)acc[v];
@@ -158,14 +203,16 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
         } else {
             double *o = reinterpret_cast<double *>(out) + p0;
             if (p0 + 4 <= n_pos) {
-                *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
-                *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);
+                f64x2 r0 = {acc[0], acc[1]}, r1 = {acc[2], acc[3]};
+                __builtin_nontemporal_store(r0, reinterpret_cast<f64x2 *>(o));
+                __builtin_nontemporal_store(r1, reinterpret_cast<f64x2 *>(o + 2));
             } else {
                 for (int v = 0; v < 4; ++v)
                     if (p0 + v < n_pos) o[v] = acc[v];
             }
         }
     }
+    if (HITS) emit_hits_block<4 * LET_ITERS>(hpass, hpos, hsq, hst, a);
 }
 
 // ---------------------------------------------------------------------------
@@ -381,19 +428,24 @@ __device__ __forceinline__ void emit_tile(const ScanArgs &a, int64_t tile0, int 
     constexpr int TILE = V * BLOCK;
     const int tid = threadIdx.x;
     const int64_t n_pos = a.n_pos;
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    if (tile0 + TILE + a.m > n_pos) {               // workgroup-uniform: only the last tile(s) of the stream
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
-    for (int v = 0; v < V; ++v)
-        if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
+        for (int v = 0; v < V; ++v)
+            if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
+    }
     if (HITS) {
+        bool hpass[V];
+        int64_t hpos[V];
+        float hsq[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const int64_t p = tile0 + la + v;
-            const float sq = (float)acc_sq[v];
-            bool pass = (p < n_pos) && (acc_st[v] > a.thr_struct);
-            if (HAS_SEQ) pass = pass && ((double)sq > a.thr_seq);
-            emit_hits(pass, p, sq, acc_st[v], a);
+            hpos[v] = tile0 + la + v;
+            hsq[v] = (float)acc_sq[v];
+            hpass[v] = (hpos[v] < n_pos) && (acc_st[v] > a.thr_struct);
+            if (HAS_SEQ) hpass[v] = hpass[v] && ((double)hsq[v] > a.thr_seq);
         }
+        emit_hits_block<V>(hpass, hpos, hsq, acc_st, a);
         return;
     }
     __syncthreads();                               // every wave is done with the tile
@@ -441,10 +493,12 @@ __device__ __forceinline__ void emit_tile_wave(const ScanArgs &a, int64_t tile0,
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t n_pos = a.n_pos;
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    if (tile0 + V * BLOCK + a.m > n_pos) {          // workgroup-uniform: only the last tile(s) of the stream
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
-    for (int v = 0; v < V; ++v)
-        if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
+        for (int v = 0; v < V; ++v)
+            if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
+    }
     const int start = ((wave * WN + a.m - 1) * 7 * (int)sizeof(PROF_T) + 15) & ~15;
     double *sto = reinterpret_cast<double *>(tile_buf + start);
     float *so = reinterpret_cast<float *>(tile_buf + start + WN * 8);
@@ -644,6 +698,15 @@ __global__ __launch_bounds__(BLOCK, 3) void k_profile_stream(const ScanArgs a, c
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// allow the kernel all of the CU's 160 KB of LDS (static part included)
+static hipError_t allow_full_lds(const void *kern)
+{
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, kern);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+}
+
 template <int NDW>
 static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
 {
@@ -673,8 +736,7 @@ static hipError_t launch_profile_inst(const ScanArgs &a, hipStream_t stream)
     auto kern = k_profile<V, HAS_SEQ, PROF_T, FINITE, HITS, DMA>;
     static bool configured = false;     // per instantiation; the attribute is sticky
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern));
         if (e != hipSuccess) return e;
         configured = true;
     }
@@ -692,8 +754,7 @@ static hipError_t launch_pipe_inst(const ScanArgs &a, const Tuning &t, hipStream
     static int per_cu = 0;              // per instantiation and LDS size class
     static int per_cu_lds = -1;
     if (per_cu_lds != lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern));
         if (e != hipSuccess) return e;
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, (size_t)lds);
@@ -723,8 +784,7 @@ static hipError_t launch_stream_inst(const ScanArgs &a, const Tuning &t, hipStre
     static int per_cu = 0;
     static int per_cu_lds = -1;
     if (per_cu_lds != lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern));
         if (e != hipSuccess) return e;
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, (size_t)lds);
