@@ -160,6 +160,21 @@ int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                       double thr_struct, int64_t capacity, int64_t *hit_pos,
                       float *hit_seq, double *hit_struct, int64_t *n_hits);
 
+/* ---- staged stream: upload once, scan with many motifs ------------------------
+ * (multi-PFM libraries, SURVEY 8f N1: the reference reloads and rescans everything
+ * per PFM file).  pfmscan_stage copies a packed stream into the ctx's device scratch
+ * and keeps it there; the *_staged calls run one motif over it without any H2D.
+ * codes / profile may be NULL when no motif that will be used needs them.  The host
+ * forms above are exactly stage + *_staged. */
+int pfmscan_stage(pfmscan_ctx *ctx, const uint8_t *codes, const void *profile,
+                  int profile_dtype, int64_t n_pos);
+int pfmscan_scan_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                        float *out_seq, double *out_struct);
+int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                        double thr_seq, double thr_struct, int64_t capacity,
+                        int64_t *hit_pos, float *hit_seq, double *hit_struct,
+                        int64_t *n_hits);
+
 /* ---- measurement helper ------------------------------------------------------
  * Average device time in milliseconds of `iters` back-to-back pfmscan_scan_dev
  * launches, bracketed by hipEvents on the launch stream (after `warmup`

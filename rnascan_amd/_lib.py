@@ -27,6 +27,7 @@ SYMBOLS = [
     "pfmscan_device_info", "pfmscan_synchronize", "pfmscan_motif_create", "pfmscan_motif_destroy",
     "pfmscan_pwm_calculate", "pfmscan_scan_dev", "pfmscan_scan_letters_f64_dev", "pfmscan_hits_dev",
     "pfmscan_scan_host", "pfmscan_scan_letters_f64_host", "pfmscan_hits_host", "pfmscan_time_scan_dev",
+    "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged",
 ]
 
 
@@ -70,6 +71,9 @@ def load():
     L.pfmscan_scan_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp]
     L.pfmscan_scan_letters_f64_host.argtypes = [vp, vp, vp, i64, vp]
     L.pfmscan_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_stage.argtypes = [vp, vp, vp, i32, i64]
+    L.pfmscan_scan_staged.argtypes = [vp, vp, vp, vp]
+    L.pfmscan_hits_staged.argtypes = [vp, vp, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_time_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, i32, i32, ctypes.POINTER(dbl)]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error"):
@@ -110,6 +114,8 @@ class Context(object):
             _raise(self._L, None, rc)
         self._h = h
         self.device = int(device)
+        self._staged_n = -1
+        self.scratch_gen = 0        # bumped whenever the ctx's device scratch is (re)written
 
     def close(self):
         if getattr(self, "_h", None):
@@ -161,6 +167,7 @@ class Context(object):
         if n < 0:
             raise MemoryError("failed to create output data")      # _pwm.c:26-31 on a negative shape
         out = np.empty(n, dtype=np.float32)
+        self.scratch_gen += 1
         self._check(self._L.pfmscan_pwm_calculate(self._h, seq, len(seq), _ptr(M), M.shape[0], _ptr(out)))
         return out
 
@@ -170,6 +177,7 @@ class Context(object):
         n, codes, profile, dt = _stream_args(motif, codes, profile)
         out_seq = np.empty(n, dtype=np.float32) if (want_seq and motif.has_letters) else None
         out_struct = np.empty(n, dtype=np.float64) if (want_struct and motif.has_struct) else None
+        self.scratch_gen += 1
         self._check(self._L.pfmscan_scan_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n,
                                               _ptr(out_seq), _ptr(out_struct)))
         return out_seq, out_struct
@@ -177,6 +185,7 @@ class Context(object):
     def scan_letters_f64_host(self, motif, codes):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         out = np.empty(codes.size, dtype=np.float64)
+        self.scratch_gen += 1
         self._check(self._L.pfmscan_scan_letters_f64_host(self._h, motif._h, _ptr(codes), codes.size, _ptr(out)))
         return out
 
@@ -185,6 +194,7 @@ class Context(object):
         Grows the buffer and retries when the first guess was too small."""
         n, codes, profile, dt = _stream_args(motif, codes, profile)
         cap = int(capacity) if capacity is not None else max(1024, n // 64)
+        self.scratch_gen += 1
         while True:
             pos = np.empty(cap, dtype=np.int64)
             sq = np.empty(cap, dtype=np.float32)
@@ -193,6 +203,58 @@ class Context(object):
             rc = self._L.pfmscan_hits_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n,
                                            float(thr_seq), float(thr_struct), cap,
                                            _ptr(pos), _ptr(sq), _ptr(st), ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
+            return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
+
+    # -- staged stream: upload once, run many motifs ------------------------------------
+    def stage(self, codes=None, profile=None):
+        """copy a packed stream into the ctx's device scratch; returns n_pos"""
+        n = None
+        dt = PROFILE_NONE
+        if codes is not None:
+            codes = np.ascontiguousarray(codes, dtype=np.uint8)
+            n = codes.size
+        if profile is not None:
+            if profile.dtype == np.float32:
+                dt = PROFILE_F32
+            elif profile.dtype == np.float64:
+                dt = PROFILE_F64
+            else:
+                raise ValueError("profile must be float32 or float64")
+            profile = np.ascontiguousarray(profile)
+            if profile.ndim != 2 or profile.shape[1] != NSTRUCT:
+                raise ValueError("profile must be [n_pos][7]")
+            if n is not None and profile.shape[0] != n:
+                raise ValueError("codes and profile disagree on n_pos")
+            n = profile.shape[0]
+        if n is None:
+            raise ValueError("nothing to stage")
+        self.scratch_gen += 1
+        self._check(self._L.pfmscan_stage(self._h, _ptr(codes), _ptr(profile), dt, n))
+        self._staged_n = n
+        return self.scratch_gen
+
+    def scan_staged(self, motif, want_seq=True, want_struct=True):
+        n = self._staged_n
+        out_seq = np.empty(n, dtype=np.float32) if (want_seq and motif.has_letters) else None
+        out_struct = np.empty(n, dtype=np.float64) if (want_struct and motif.has_struct) else None
+        self._check(self._L.pfmscan_scan_staged(self._h, motif._h, _ptr(out_seq), _ptr(out_struct)))
+        return out_seq, out_struct
+
+    def hits_staged(self, motif, thr_seq=-np.inf, thr_struct=-np.inf, capacity=None):
+        n = self._staged_n
+        cap = int(capacity) if capacity is not None else max(1024, n // 64)
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            sq = np.empty(cap, dtype=np.float32)
+            st = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_hits_staged(self._h, motif._h, float(thr_seq), float(thr_struct), cap,
+                                             _ptr(pos), _ptr(sq), _ptr(st), ctypes.byref(k))
             if rc == E_CAPACITY and capacity is None:
                 cap = int(k.value)
                 continue

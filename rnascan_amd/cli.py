@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-from . import fasta, pack, pssm as pssm_mod, scanner, shard
+from . import fasta, pack, pssm as pssm_mod, scanner, shard, store
 
 __version__ = "0.10.2+mi355x.1"
 
@@ -95,7 +95,8 @@ def load_motif(pfm_file, pseudocount, letters, background):
     fasta.eprint("Loading PFM %s" % pfm_file, end="")
     tic = time.time()
     try:
-        motifs_set[pssm_mod.motif_id_of(pfm_file)] = pssm_mod.pfm2pssm(pfm_file, pseudocount, letters, background)
+        # a multi-PFM library (pfmutil.py:115-133 format) yields one motif per block; every one is scanned
+        motifs_set.update(pssm_mod.load_pssms(pfm_file, pseudocount, letters, background))
     except ValueError:
         fasta.eprint("\nFailed to load motif %s" % pfm_file)
     except KeyError:
@@ -123,6 +124,15 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None)):
         df["Sequence_ID"] = "testseq"
         df["Description"] = ""
         fasta.eprint("Processed %d sequences" % 1)
+        return df
+    if store.is_store(source):
+        # packed profile store: the mapped file is already the stream the kernel reads
+        fasta.eprint("Scanning averaged secondary structures ")
+        ps = store.ProfileStore(source)
+        lo, hi = shard.partition(ps.lengths, world)[rank]
+        df = shard.gather_frames(scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing, lo, hi),
+                                 rank, world, dist)
+        fasta.eprint("Processed %d sequences" % len(ps.ids))
         return df
     if os.path.isdir(source):
         fasta.eprint("Scanning averaged secondary structures ")

@@ -30,6 +30,10 @@ struct pfmscan_ctx {
     int64_t hbm = 0;
     char name[128] = {0};
     DevBuf codes, profile, out_seq, out_struct, hit_pos, hit_seq, hit_struct, count, table;
+    // staged stream (pfmscan_stage)
+    int64_t staged_n = -1;
+    int staged_dtype = PFMSCAN_PROFILE_NONE;
+    bool staged_codes = false, staged_profile = false;
 };
 
 struct pfmscan_motif {
@@ -305,18 +309,19 @@ int pfmscan_hits_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d
     return do_launch(ctx, a, stream);
 }
 
-// ---- host-buffer forms ---------------------------------------------------------
-static int stage_inputs(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
-                        int profile_dtype, int64_t n_pos)
+// ---- staged stream + host-buffer forms -------------------------------------------
+int pfmscan_stage(pfmscan_ctx *ctx, const uint8_t *codes, const void *profile, int profile_dtype, int64_t n_pos)
 {
-    if (mo->d_letters) {
-        if (!codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (!ctx) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx");
+    if (n_pos < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
+    ctx->staged_n = -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (codes && n_pos > 0) {
         int rc = ensure(ctx, ctx->codes, (size_t)n_pos);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->codes.p, codes, (size_t)n_pos, hipMemcpyHostToDevice, ctx->stream));
     }
-    if (mo->d_struct) {
-        if (!profile) return fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
+    if (profile && n_pos > 0) {
         if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
             return fail(ctx, PFMSCAN_E_BADARG, "profile_dtype must be F32 or F64");
         size_t bytes = (size_t)n_pos * 7 * (profile_dtype == PFMSCAN_PROFILE_F32 ? 4 : 8);
@@ -324,6 +329,39 @@ static int stage_inputs(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->profile.p, profile, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller may reuse its buffers
+    ctx->staged_n = n_pos;
+    ctx->staged_dtype = profile ? profile_dtype : PFMSCAN_PROFILE_NONE;
+    ctx->staged_codes = codes != nullptr;
+    ctx->staged_profile = profile != nullptr;
+    return PFMSCAN_OK;
+}
+
+static int check_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo)
+{
+    if (!ctx || !mo) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
+    if (ctx->staged_n < 0) return fail(ctx, PFMSCAN_E_BADARG, "no stream staged (call pfmscan_stage first)");
+    if (mo->d_letters && !ctx->staged_codes && ctx->staged_n > 0) return fail(ctx, PFMSCAN_E_BADARG, "motif has a letter table but no codes are staged");
+    if (mo->d_struct && !ctx->staged_profile && ctx->staged_n > 0) return fail(ctx, PFMSCAN_E_BADARG, "motif has a structure PSSM but no profile is staged");
+    return PFMSCAN_OK;
+}
+
+int pfmscan_scan_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, float *out_seq, double *out_struct)
+{
+    int rc = check_staged(ctx, mo);
+    if (rc) return rc;
+    const int64_t n_pos = ctx->staged_n;
+    if (n_pos == 0) return PFMSCAN_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (out_seq && (rc = ensure(ctx, ctx->out_seq, (size_t)n_pos * 4))) return rc;
+    if (out_struct && (rc = ensure(ctx, ctx->out_struct, (size_t)n_pos * 8))) return rc;
+    rc = pfmscan_scan_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos,
+                          out_seq ? (float *)ctx->out_seq.p : nullptr, out_struct ? (double *)ctx->out_struct.p : nullptr,
+                          ctx->stream);
+    if (rc) return rc;
+    if (out_seq) HIP_TRY(ctx, hipMemcpyAsync(out_seq, ctx->out_seq.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_struct) HIP_TRY(ctx, hipMemcpyAsync(out_struct, ctx->out_struct.p, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PFMSCAN_OK;
 }
 
@@ -333,19 +371,11 @@ int pfmscan_scan_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *
     if (!ctx || !mo) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
     if (n_pos < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
     if (n_pos == 0) return PFMSCAN_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = stage_inputs(ctx, mo, codes, profile, profile_dtype, n_pos);
+    if (mo->d_letters && !codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (mo->d_struct && !profile) return fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
+    int rc = pfmscan_stage(ctx, mo->d_letters ? codes : nullptr, mo->d_struct ? profile : nullptr, profile_dtype, n_pos);
     if (rc) return rc;
-    if (out_seq && (rc = ensure(ctx, ctx->out_seq, (size_t)n_pos * 4))) return rc;
-    if (out_struct && (rc = ensure(ctx, ctx->out_struct, (size_t)n_pos * 8))) return rc;
-    rc = pfmscan_scan_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, profile_dtype, n_pos,
-                          out_seq ? (float *)ctx->out_seq.p : nullptr, out_struct ? (double *)ctx->out_struct.p : nullptr,
-                          ctx->stream);
-    if (rc) return rc;
-    if (out_seq) HIP_TRY(ctx, hipMemcpyAsync(out_seq, ctx->out_seq.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_struct) HIP_TRY(ctx, hipMemcpyAsync(out_struct, ctx->out_struct.p, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PFMSCAN_OK;
+    return pfmscan_scan_staged(ctx, mo, out_seq, out_struct);
 }
 
 int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, int64_t n_pos, double *out)
@@ -356,6 +386,7 @@ int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, con
     if (n_pos == 0) return PFMSCAN_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    ctx->staged_n = -1;                                   // the scratch is about to be overwritten
     int rc = ensure(ctx, ctx->codes, (size_t)n_pos);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->codes.p, codes, (size_t)n_pos, hipMemcpyHostToDevice, ctx->stream));
@@ -367,24 +398,24 @@ int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, con
     return PFMSCAN_OK;
 }
 
-int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
-                      int profile_dtype, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
-                      int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
+int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, double thr_seq, double thr_struct, int64_t capacity,
+                        int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
 {
-    if (!ctx || !mo || !n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
-    if (n_pos < 0 || capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    if (!n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    int rc = check_staged(ctx, mo);
+    if (rc) return rc;
+    if (capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
     *n_hits = 0;
+    const int64_t n_pos = ctx->staged_n;
     if (n_pos == 0) return PFMSCAN_OK;
     if (capacity > 0 && !hit_pos) return fail(ctx, PFMSCAN_E_BADARG, "hit_pos is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = stage_inputs(ctx, mo, codes, profile, profile_dtype, n_pos);
-    if (rc) return rc;
     if ((rc = ensure(ctx, ctx->hit_pos, (size_t)std::max<int64_t>(capacity, 1) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->hit_seq, (size_t)std::max<int64_t>(capacity, 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hit_struct, (size_t)std::max<int64_t>(capacity, 1) * 8))) return rc;
     if ((rc = ensure(ctx, ctx->count, 8))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->count.p, 0, 8, ctx->stream));
-    rc = pfmscan_hits_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, profile_dtype, n_pos, thr_seq, thr_struct,
+    rc = pfmscan_hits_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq, thr_struct,
                           capacity, (int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p, (double *)ctx->hit_struct.p,
                           (uint64_t *)ctx->count.p, ctx->stream);
     if (rc) return rc;
@@ -410,6 +441,21 @@ int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *
         if (hit_struct) hit_struct[i] = mo->d_struct ? st[order[i]] : NAN;
     }
     return PFMSCAN_OK;
+}
+
+int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
+                      int profile_dtype, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
+                      int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    if (!ctx || !mo || !n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (n_pos < 0 || capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (mo->d_letters && !codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (mo->d_struct && !profile) return fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
+    int rc = pfmscan_stage(ctx, mo->d_letters ? codes : nullptr, mo->d_struct ? profile : nullptr, profile_dtype, n_pos);
+    if (rc) return rc;
+    return pfmscan_hits_staged(ctx, mo, thr_seq, thr_struct, capacity, hit_pos, hit_seq, hit_struct, n_hits);
 }
 
 // ---- the reference's native entry point ------------------------------------------

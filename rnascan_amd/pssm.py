@@ -115,5 +115,55 @@ def pfm2pssm(pfm_file, pseudocount, letters, background=None):
     return PSSM(letters, log_odds(normalize(counts, pseudocount), background))
 
 
+def is_multi_pfm(pfm_file):
+    """multi-PFM files (pfmutil.py:115-133) start with a ``#id`` line"""
+    with open(pfm_file) as fh:
+        return fh.readline().startswith("#")
+
+
+def read_multi_pfm(pfm_file):
+    """The reference's multi-PFM format (reader pfmutil.py:89-113, writer :115-133):
+    blocks of ``#<id>`` / ``#PO\t<letters>`` header lines followed by rows
+    ``<pos>\t<v>...``, separated by blank lines.  Yields (id, OrderedDict letter -> array)."""
+    with open(pfm_file) as fh:
+        lines = [ln.rstrip("\r\n") for ln in fh]
+    i, n = 0, len(lines)
+    while i < n:
+        if not lines[i].startswith("#"):
+            i += 1
+            continue
+        header = []
+        while i < n and lines[i].startswith("#"):
+            header.append(lines[i][1:])
+            i += 1
+        if len(header) < 2:
+            raise ValueError("multi-PFM block without a #PO header line in %s" % pfm_file)
+        motif_id = header[0]
+        letters = header[1].split("\t")[1:]
+        cols = [[] for _ in letters]
+        while i < n and not lines[i].startswith("#"):
+            row = lines[i].rstrip()
+            i += 1
+            if not row:
+                continue
+            parts = row.split("\t")
+            for k in range(len(letters)):
+                cols[k].append(float(parts[k + 1]))
+        yield motif_id, OrderedDict((l, np.array(c, dtype=np.float64)) for l, c in zip(letters, cols))
+
+
+def load_pssms(pfm_file, pseudocount, letters, background=None):
+    """OrderedDict motif id -> PSSM for a single-PFM file (one entry, id from the file
+    name as rnascan.py:217) or a multi-PFM library (one entry per block)."""
+    out = OrderedDict()
+    if is_multi_pfm(pfm_file):
+        for motif_id, counts in read_multi_pfm(pfm_file):
+            counts = OrderedDict((l, counts[l]) for l in letters)
+            out[motif_id] = PSSM(letters, log_odds(normalize(counts, pseudocount), background))
+    else:
+        out[motif_id_of(pfm_file)] = pfm2pssm(pfm_file, pseudocount, letters, background)
+    return out
+
+
 def motif_id_of(pfm_file):
     return os.path.splitext(os.path.basename(pfm_file))[0]      # rnascan.py:217

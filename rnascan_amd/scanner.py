@@ -22,19 +22,30 @@ SEQ_COLUMNS = ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequen
 
 
 class HipEngine(object):
-    """Scores packed streams on one MI355X through the C ABI (include/pfmscan.h)."""
+    """Scores packed streams on one MI355X through the C ABI (include/pfmscan.h).
+
+    The last stream stays staged on the device: scanning the same ``Stream`` object
+    with another motif (a multi-PFM library) re-uses it without any upload."""
 
     def __init__(self, device=0):
         self.ctx = _lib.Context(device)
+        self._staged = None
 
     def close(self):
         self.ctx.close()
+
+    def _stage(self, stream):
+        if self._staged is None or self._staged[0] is not stream or self._staged[1] != self.ctx.scratch_gen:
+            self._staged = None
+            gen = self.ctx.stage(stream.codes, stream.profile)
+            self._staged = (stream, gen)
 
     def scan(self, stream, letter_table=None, struct_pssm=None):
         """all window scores, position aligned -> (float32 seq | None, float64 struct | None)"""
         motif = self.ctx.motif(letter_table, struct_pssm)
         try:
-            return self.ctx.scan_host(motif, stream.codes, stream.profile)
+            self._stage(stream)
+            return self.ctx.scan_staged(motif)
         finally:
             motif.close()
 
@@ -42,6 +53,7 @@ class HipEngine(object):
         """generic-alphabet letter scores in fp64 (matrix.py:25-43)"""
         motif = self.ctx.motif(letter_table, None)
         try:
+            self._staged = None
             return self.ctx.scan_letters_f64_host(motif, stream.codes)
         finally:
             motif.close()
@@ -50,7 +62,8 @@ class HipEngine(object):
         """positions (sorted) whose scores exceed the thresholds -> (pos, seq | None, struct | None)"""
         motif = self.ctx.motif(letter_table, struct_pssm)
         try:
-            return self.ctx.hits_host(motif, stream.codes, stream.profile, thr_seq, thr_struct)
+            self._stage(stream)
+            return self.ctx.hits_staged(motif, thr_seq, thr_struct)
         finally:
             motif.close()
 
@@ -91,10 +104,10 @@ def scan_records(engine, records, pssm, letters, minscore):
     records: iterable of fasta.Record; letters: the alphabet's letters (``GAUC``
     for RNA, ``EHTBLRM`` for structure strings).  Returns the hit table with the
     reference's columns, rows in record order then by Start."""
-    motif_id, pm = _first_motif(pssm)
-    m = pm.length
     is_rna = fasta.is_rna_letters(letters)
     recs = list(records)
+    if not recs:
+        return pd.DataFrame(columns=SEQ_COLUMNS)
     seqs = [fasta.preprocess_seq(r.seq, is_rna) for r in recs]
     if is_rna:
         order = pack.RNA_LETTERS                               # sorted(alphabet.letters), matrix.py:57
@@ -102,25 +115,36 @@ def scan_records(engine, records, pssm, letters, minscore):
     else:
         order = letters
         codes = [pack.encode_letters(s, order) for s in seqs]   # _py_calculate upper-cases, matrix.py:31
-    table = pm.letter_table(order)
-    if not recs:
-        return pd.DataFrame(columns=SEQ_COLUMNS)
-    stream = pack.pack(codes)
-    if is_rna:
-        pos, sq, _ = _select(engine, stream, m, table, None, float(minscore), -np.inf)
-        logodds = np.round(sq, 3)                              # round(np.float32, 3) stays float32 (rnascan.py:273)
+    stream = pack.pack(codes)                                  # packed (and staged on the device) once
+    frames = []
+    for motif_id, pm in pssm.items():                          # the reference's dict only ever holds one (:262)
+        m = pm.length
+        table = pm.letter_table(order)
+        if is_rna:
+            pos, sq, _ = _select(engine, stream, m, table, None, float(minscore), -np.inf)
+            logodds = np.round(sq, 3)                          # round(np.float32, 3) stays float32 (rnascan.py:273)
+        else:
+            full = engine.scan_letters_f64(stream, table)       # Python floats in the reference: fp64, no f32 cast
+            keep = stream.window_mask(m) & (full > float(minscore))
+            pos = np.flatnonzero(keep)
+            logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
+        rec, start = stream.locate(pos)
+        frag = [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
+        frames.append(pd.DataFrame({"_rec": rec, "Sequence_ID": [recs[r].id for r in rec.tolist()],
+                                    "Description": [recs[r].description for r in rec.tolist()], "Motif_ID": motif_id,
+                                    "Start": start + 1, "End": start + m, "Sequence": frag, "LogOdds": logodds}))
+    return _merge_motif_frames(frames)
+
+
+def _merge_motif_frames(frames):
+    """one table per motif -> record order, then sort_values(['Start', 'Motif_ID']) inside a
+    record (rnascan.py:286); with one motif this is the identity"""
+    if len(frames) == 1:
+        df = frames[0]
     else:
-        full = engine.scan_letters_f64(stream, table)           # Python floats in the reference: fp64, no f32 cast
-        keep = stream.window_mask(m) & (full > float(minscore))
-        pos = np.flatnonzero(keep)
-        logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
-    rec, start = stream.locate(pos)
-    frag = [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
-    ids = [recs[r].id for r in rec.tolist()]
-    desc = [recs[r].description for r in rec.tolist()]
-    return pd.DataFrame({"Sequence_ID": ids, "Description": desc, "Motif_ID": motif_id,
-                         "Start": start + 1, "End": start + m, "Sequence": frag, "LogOdds": logodds},
-                        columns=SEQ_COLUMNS)
+        df = pd.concat(frames, ignore_index=True)
+        df = df.sort_values(["_rec", "Start", "Motif_ID"], kind="stable").reset_index(drop=True)
+    return df[SEQ_COLUMNS]
 
 
 def scan(engine, pssm, seq, letters, minscore):
@@ -154,25 +178,42 @@ def struct_matrix(pm, file_letters, pairing="aligned"):
     raise ValueError("pairing must be 'aligned' or 'positional'")
 
 
+def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing):
+    """hit table of a packed profile stream (no codes): rnascan.py:302-315 for every record
+    (and for every motif of a library; the stream is staged on the device once)"""
+    frames = []
+    for motif_id, pm in pssm.items():
+        m = pm.length
+        P = struct_matrix(pm, list(letters), pairing)
+        pos, _, st = _select(engine, stream, m, None, P, -np.inf, float(minscore))
+        rec, start = stream.locate(pos)
+        frames.append(pd.DataFrame({"_rec": rec, "Sequence_ID": [ids[r] for r in rec.tolist()], "Description": "",
+                                    "Motif_ID": motif_id, "Start": start + 1, "End": start + m, "Sequence": ".",
+                                    "LogOdds": st}))
+    return _merge_motif_frames(frames)
+
+
 def scan_profiles(engine, named_profiles, pssm, minscore, pairing="aligned", profile_dtype=np.float32):
     """Batch form of scan_averaged_structure (rnascan.py:293-315) + the tagging of
     scan_main (:367-374).  named_profiles: list of (Sequence_ID, letters, [L][7])."""
-    motif_id, pm = _first_motif(pssm)
-    m = pm.length
-    cols = SEQ_COLUMNS
     if not named_profiles:
-        return pd.DataFrame(columns=cols)
+        return pd.DataFrame(columns=SEQ_COLUMNS)
     letters0 = list(named_profiles[0][1])
-    P = struct_matrix(pm, letters0, pairing)
     for _, letters, _ in named_profiles:
         if list(letters) != letters0:
             raise ValueError("averaged-structure files disagree on their column order")
     stream = pack.pack(profiles=[p for _, _, p in named_profiles], profile_dtype=profile_dtype)
-    pos, _, st = _select(engine, stream, m, None, P, -np.inf, float(minscore))
-    rec, start = stream.locate(pos)
-    ids = [named_profiles[r][0] for r in rec.tolist()]
-    return pd.DataFrame({"Sequence_ID": ids, "Description": "", "Motif_ID": motif_id, "Start": start + 1,
-                         "End": start + m, "Sequence": ".", "LogOdds": st}, columns=cols)
+    return _scan_profile_stream(engine, stream, [n for n, _, _ in named_profiles], letters0, pssm, minscore, pairing)
+
+
+def scan_store(engine, profile_store, pssm, minscore, pairing="aligned", lo=0, hi=None):
+    """Same table from a packed profile store (rnascan_amd/store.py): the mapped file
+    already IS the stream layout, nothing is parsed or repacked."""
+    hi = len(profile_store.ids) if hi is None else hi
+    if hi <= lo:
+        return pd.DataFrame(columns=SEQ_COLUMNS)
+    return _scan_profile_stream(engine, profile_store.stream(lo, hi), profile_store.ids[lo:hi], profile_store.letters,
+                                pssm, minscore, pairing)
 
 
 def scan_averaged_structure(engine, struct_file, pssm, minscore, pairing="aligned", profile_dtype=np.float64):
@@ -274,6 +315,9 @@ def _add_match_id(df):
 
 
 def load_profile_dir(directory):
+    from . import store
+    if store.is_store(directory):
+        return store.ProfileStore(directory).named()
     named = []
     for sid, path in fasta.list_profiles(directory):
         letters, prof = fasta.read_profile(path)

@@ -99,3 +99,48 @@ def test_scanner_layer_gpu_equals_oracle_engine(engine):
         s1 = scanner.scan_records(engine, recs, sp, fasta.RNA, thr)
         s2 = scanner.scan_records(OracleEngine(), recs, sp, fasta.RNA, thr)
         pd.testing.assert_frame_equal(s1, s2)
+
+
+def test_multi_pfm_library_on_gpu_reuses_the_staged_stream(engine, tmp_path):
+    """N1 on the device: the packed stream is uploaded once (ctx scratch generation does not
+    move between motifs) and every motif's table equals the oracle engine's"""
+    import pandas as pd
+    from engines import OracleEngine
+    from rnascan_amd import fasta, pssm, scanner
+    from test_scanner_cpu import _write_multi_pfm
+    rng = np.random.default_rng(3)
+    motifs = [("M%03d" % k, list("ACGU"), rng.dirichlet(np.full(4, 0.5), size=int(rng.integers(6, 19)))) for k in range(8)]
+    lib = str(tmp_path / "lib.pfm")
+    _write_multi_pfm(lib, motifs)
+    P = pssm.load_pssms(lib, 0.01, fasta.RNA, None)
+    recs = [fasta.Record("r%d" % i, "r%d" % i, "".join(rng.choice(list("ACGTN"), size=int(rng.integers(0, 2000)))))
+            for i in range(50)]
+    g0 = engine.ctx.scratch_gen
+    got = scanner.scan_records(engine, recs, P, fasta.RNA, 2.0)
+    assert engine.ctx.scratch_gen == g0 + 1                     # one upload for 8 motifs
+    want = scanner.scan_records(OracleEngine(), recs, P, fasta.RNA, 2.0)
+    pd.testing.assert_frame_equal(got, want)
+    assert got["Motif_ID"].nunique() == 8
+
+
+def test_staged_api_matches_host_api(ctx, oracle):
+    from rnascan_amd import pack
+    from test_gpu_parity import rand_stream, rand_table, rand_struct_pssm
+    from conftest import assert_f32_bits_equal, assert_struct_close
+    rng = np.random.default_rng(77)
+    s = rand_stream(rng, 30, 0, 800)
+    ctx.stage(s.codes, s.profile)
+    for m in (5, 12, 20):
+        T, P = rand_table(rng, m), rand_struct_pssm(rng, m, inf_frac=0.1)
+        motif = ctx.motif(T, P)
+        sq, st = ctx.scan_staged(motif)
+        assert_f32_bits_equal(sq, oracle.stream_seq(s.codes, T))
+        assert_struct_close(st, oracle.stream_struct(s.profile, P))
+        pos, hs, hst = ctx.hits_staged(motif, 0.0, -40.0)
+        want = oracle.stream_hits(oracle.stream_seq(s.codes, T), oracle.stream_struct(s.profile, P), 0.0, -40.0)
+        assert np.array_equal(pos, want)
+        motif.close()
+    with pytest.raises(ValueError):
+        only_seq = ctx.motif(letter_table=rand_table(rng, 4))
+        ctx.stage(None, s.profile)
+        ctx.hits_staged(only_seq, 0.0, 0.0)

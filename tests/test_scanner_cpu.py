@@ -166,3 +166,83 @@ def test_cli_modes_and_errors(tmp_path, capsys):
         cli.main(["-p", SEQ_PFM, "-g", HIST_FA], engine=OracleEngine(), out=io.StringIO())   # --bgonly prints and exits
     err = capsys.readouterr().err
     assert "Loading PFM" in err and "Found 1 motifs" in err and "Scanning sequences" in err and "Processed 1 sequences" in err
+
+
+def test_profile_store_roundtrip_and_scan(tmp_path, avgdir):
+    """N2: packed profile store == parsing the text files, through scanner and CLI"""
+    from rnascan_amd import store
+    rng = np.random.default_rng(5)
+    d = tmp_path / "many"
+    d.mkdir()
+    shutil.copyfile(HIST_PROFILE, d / "structure.hg19_dna.txt")
+    for i in range(6):
+        L = int(rng.integers(5, 80))
+        prof = rng.dirichlet(np.full(7, 0.3), size=L)
+        with open(d / ("structure.r%d.txt" % i), "w") as f:
+            f.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+            for k, row in enumerate(prof):
+                f.write(str(k) + "\t" + "\t".join(str(float(x)) for x in row) + "\n")
+    sdir = str(tmp_path / "store")
+    assert store.main([str(d), sdir]) == 0 and store.is_store(sdir) and not store.is_store(str(d))
+    ps = store.ProfileStore(sdir)
+    assert ps.ids == sorted(ps.ids) and len(ps.ids) == 7 and ps.letters == list("BEHLMRT")
+    letters, prof = fasta.read_profile(HIST_PROFILE)
+    k = ps.ids.index("hg19_dna")
+    assert np.array_equal(np.asarray(ps.named()[k][2]), prof)
+    st = ps.stream()
+    assert st.n_pos == ps.n_pos and np.array_equal(st.profile[ps.offsets + ps.lengths], np.zeros((7, 7)))
+    sub = ps.stream(2, 5)
+    assert sub.n_records == 3 and sub.offsets[0] == 0 and sub.n_pos == int((ps.lengths[2:5] + 1).sum())
+    P = {"SLBP_struct": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    a = scanner.scan_store(OracleEngine(), ps, P, -10.0)
+    named = sorted(scanner.load_profile_dir(str(d)))
+    b = scanner.scan_profiles(OracleEngine(), named, P, -10.0, "aligned", np.float64)
+    pd.testing.assert_frame_equal(a, b)
+    o1, o2 = io.StringIO(), io.StringIO()
+    cli.main(["-q", STRUCT_PFM, "-u", "-m", "-10", sdir], engine=OracleEngine(), out=o1)
+    cli.main(["-q", STRUCT_PFM, "-u", "-m", "-10", str(d)], engine=OracleEngine(), out=o2)
+    rows = lambda t: sorted(l.split("\t")[:-1] for l in t.splitlines()[1:])      # Match_ID depends on glob order
+    assert rows(o1.getvalue()) == rows(o2.getvalue()) and len(rows(o1.getvalue())) > 5
+
+
+def _write_multi_pfm(path, motifs):
+    """writer of the reference's multi-PFM format (pfmutil.py:115-133)"""
+    with open(path, "w") as f:
+        for mid, letters, M in motifs:
+            f.write("#" + mid + "\n#PO" + "".join("\t" + l for l in letters) + "\n")
+            for i, row in enumerate(M):
+                f.write(str(i) + "".join("\t" + str(float(x)) for x in row) + "\n")
+            f.write("\n")
+
+
+def test_multi_pfm_library_equals_one_scan_per_motif(tmp_path):
+    """N1: a multi-PFM library scanned in one go == scanning each PFM on its own"""
+    rng = np.random.default_rng(21)
+    motifs = [("M%03d" % k, list("ACGU"), rng.dirichlet(np.full(4, 0.5), size=int(rng.integers(6, 13)))) for k in range(5)]
+    lib = str(tmp_path / "lib.pfm")
+    _write_multi_pfm(lib, motifs)
+    assert pssm.is_multi_pfm(lib) and not pssm.is_multi_pfm(SEQ_PFM)
+    got = list(pssm.read_multi_pfm(lib))
+    assert [g[0] for g in got] == [m[0] for m in motifs]
+    for (mid, counts), (_, letters, M) in zip(got, motifs):
+        assert list(counts.keys()) == letters and np.array_equal(np.stack([counts[l] for l in letters], 1), M)
+    P = pssm.load_pssms(lib, 0.01, fasta.RNA, None)
+    assert list(P.keys()) == [m[0] for m in motifs]
+    recs = [fasta.Record("r%d" % i, "r%d" % i, "".join(rng.choice(list("ACGT"), size=int(rng.integers(20, 300)))))
+            for i in range(12)]
+    eng = OracleEngine()
+    both = scanner.scan_records(eng, recs, P, fasta.RNA, 1.0)
+    singles = pd.concat([scanner.scan_records(eng, recs, {k: v}, fasta.RNA, 1.0) for k, v in P.items()], ignore_index=True)
+    assert len(both) == len(singles) > 20
+    key = ["Sequence_ID", "Start", "Motif_ID"]
+    rid = {r.id: i for i, r in enumerate(recs)}
+    singles = singles.assign(_r=singles["Sequence_ID"].map(rid)).sort_values(["_r", "Start", "Motif_ID"], kind="stable")
+    pd.testing.assert_frame_equal(both.reset_index(drop=True), singles.drop(columns="_r").reset_index(drop=True))
+    # per record the rows are ordered like sort_values(['Start', 'Motif_ID']) (rnascan.py:286)
+    for _, g in both.groupby("Sequence_ID", sort=False):
+        assert g[["Start", "Motif_ID"]].values.tolist() == sorted(g[["Start", "Motif_ID"]].values.tolist())
+    out = io.StringIO()
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(">%s\n%s\n" % (r.id, r.seq) for r in recs))
+    cli.main(["-p", lib, "-u", "-C", "0.01", "-m", "1", str(fa)], engine=eng, out=out)
+    assert len(out.getvalue().splitlines()) == len(both) + 1
