@@ -122,11 +122,9 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     }
     if (const char *v = std::getenv("PFMSCAN_V")) {
         int x = std::atoi(v);
-        if (x == 3 || x == 5 || x == 7) ctx->tune.v = x;
+        if (x == 5 || x == 7) ctx->tune.v = x;
     }
     if (const char *v = std::getenv("PFMSCAN_DMA")) ctx->tune.dma = std::atoi(v) != 0;
-    if (const char *v = std::getenv("PFMSCAN_PIPE")) ctx->tune.pipe = std::atoi(v);
-    if (const char *v = std::getenv("PFMSCAN_BLOCKS_PER_CU")) ctx->tune.blocks_per_cu = std::atoi(v);
     if (const char *v = std::getenv("PFMSCAN_ABLATE")) ctx->tune.ablate = std::atoi(v);
     *out = ctx;
     return PFMSCAN_OK;

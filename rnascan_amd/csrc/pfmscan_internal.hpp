@@ -34,13 +34,10 @@ struct ScanArgs {
 // Tuning knobs settable through the environment (read once per ctx), so that
 // variants can be A/B-timed on the GPU box without a rebuild.
 struct Tuning {
-    int v = 5;              // windows per thread in the profile kernels: 3, 5 or 7 (odd: conflict-free LDS rows)
+    int v = 5;              // windows per thread in k_profile: 5 or 7 (odd: conflict-free LDS rows)
     int dma = 1;            // k_profile: stage the tile with LDS-DMA (global_load_lds, 2.34 ms on C3) instead of
                             // through registers (2.51 ms)
-    int pipe = 0;           // 0: one tile per workgroup (k_profile, the default: 2.6 ms on C3), 1: persistent
-                            // double-buffered k_profile_pipe (3.4 ms: LDS allows only 8 waves/CU)
     int ablate = 0;         // see ScanArgs::ablate; results are WRONG when non-zero
-    int blocks_per_cu = 0;  // k_profile_pipe: cap on resident workgroups per CU (0 = what fits)
 };
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// k_profile / k_profile_pipe
+// k_profile
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
@@ -274,7 +274,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p)
 // LDS buffer.  Interior tiles: LDS-DMA (DMA) or 16-byte register staging;
 // tiles that touch the end of the stream: dword loads with zero / SEP fill.
 // Returns nothing; completion is observed by the caller's vmcnt(0) + barrier.
-template <int V, bool HAS_SEQ, typename PROF_T, int DMA>   // DMA: 0 registers, 1 builtin LDS-DMA, 2 asm LDS-DMA
+template <int V, bool HAS_SEQ, typename PROF_T, int DMA>   // DMA: 0 = through registers, 2 = LDS-DMA (inline asm)
 __device__ __forceinline__ void stage_tile(const ScanArgs &a, int64_t tile0, unsigned char *buf, int m)
 {
     using L = ProfileLayout<V, PROF_T>;
@@ -299,23 +299,6 @@ __device__ __forceinline__ void stage_tile(const ScanArgs &a, int64_t tile0, uns
                 const int ncp = code_bytes >> 10;
                 for (int pc = wave; pc < ncp; pc += BLOCK / 64)
                     dma_issue16(csrc + ((size_t)pc << 10) + (lane << 4), base + (uint32_t)prof_bytes + ((uint32_t)pc << 10));
-            }
-        } else if (DMA == 1) {
-            const int wave = tid >> 6, lane = tid & 63;
-            const int npiece = prof_bytes >> 10;
-            for (int pc = wave; pc < npiece; pc += BLOCK / 64) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) uint32_t *)(gsrc + ((size_t)pc << 10) + (lane << 4)),
-                    (__attribute__((address_space(3))) uint32_t *)(buf + ((size_t)pc << 10)), 16, 0, 0);
-            }
-            if (HAS_SEQ) {
-                const unsigned char *csrc = a.codes + tile0;
-                const int ncp = code_bytes >> 10;
-                for (int pc = wave; pc < ncp; pc += BLOCK / 64) {
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) uint32_t *)(csrc + ((size_t)pc << 10) + (lane << 4)),
-                        (__attribute__((address_space(3))) uint32_t *)(buf + prof_bytes + ((size_t)pc << 10)), 16, 0, 0);
-                }
             }
         } else {
             // register staging, 4 x 16 B per thread in flight per round (measured faster
@@ -584,117 +567,6 @@ __global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_prof
         emit_tile_wave<V, HAS_SEQ, PROF_T>(a, tile0, la, acc_st, acc_sq, smem);
 }
 
-// Persistent, double-buffered form: a workgroup walks tiles b, b+G, b+2G, ...
-// and keeps the NEXT tile's LDS-DMA in flight while it scores the current one,
-// so a whole tile (36-50 KB) per workgroup is always outstanding towards HBM.
-template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
-__global__ __launch_bounds__(BLOCK) void k_profile_pipe(const ScanArgs a, const int n_tiles)
-{
-    using L = ProfileLayout<V, PROF_T>;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int m = a.m;
-    const int prof_bytes = L::prof_bytes(m);
-    const int buf_bytes = L::buf_bytes(m, HAS_SEQ);
-    char *tseq_lds = reinterpret_cast<char *>(smem + 2 * buf_bytes);
-    if (HAS_SEQ)
-        for (int i = threadIdx.x; i < m * 8; i += BLOCK) reinterpret_cast<double *>(tseq_lds)[i] = a.letter_table[i];
-    const int la = threadIdx.x * V;
-    int t = blockIdx.x;
-    if (t < n_tiles) stage_tile<V, HAS_SEQ, PROF_T, 2>(a, (int64_t)t * L::TILE, smem, m);
-    int cur = 0;
-#pragma unroll 1
-    for (; t < n_tiles; t += gridDim.x) {
-        unsigned char *buf = smem + cur * buf_bytes;
-        dma_wait_all();                            // this wave's share of tile t has landed ...
-        __syncthreads();                           // ... and everybody's; the other buffer is free
-        const int tn = t + gridDim.x;
-        if (tn < n_tiles) stage_tile<V, HAS_SEQ, PROF_T, 2>(a, (int64_t)tn * L::TILE, smem + (cur ^ 1) * buf_bytes, m);
-        double acc_st[V], acc_sq[V];
-        compute_tile<V, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(buf), buf + prof_bytes, tseq_lds,
-                                                 a.struct_pssm, m, la, acc_st, acc_sq);
-        emit_tile<V, HAS_SEQ, HITS>(a, (int64_t)t * L::TILE, la, acc_st, acc_sq, buf);
-        cur ^= 1;
-    }
-}
-
-// Persistent, register-prefetched form ("issue early / write late"): a workgroup
-// walks tiles b, b+G, ...; at the top of an iteration every thread issues ALL of its
-// 16-byte loads of the NEXT tile into registers, scores the current tile out of LDS
-// while those loads are in flight, then (after the outputs left through the same LDS
-// buffer) writes the registers into LDS.  One LDS buffer per workgroup, so residency
-// stays at 3 workgroups / 12 waves per CU, and every workgroup has a whole tile
-// outstanding towards HBM for the whole scoring phase.
-template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
-__global__ __launch_bounds__(BLOCK, 3) void k_profile_stream(const ScanArgs a, const int n_tiles)
-{
-    using L = ProfileLayout<V, PROF_T>;
-    constexpr int MAXCH = (L::prof_bytes(PFMSCAN_MAX_M) / 16 + BLOCK - 1) / BLOCK;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int m = a.m;
-    const int tid = threadIdx.x;
-    const int64_t n_pos = a.n_pos;
-    const int prof_bytes = L::prof_bytes(m);
-    const int code_bytes = L::code_bytes(m);
-    const int nch = prof_bytes >> 4, ncc = code_bytes >> 4;
-    const int64_t total_bytes = n_pos * 7 * (int64_t)sizeof(PROF_T);
-    char *tseq_lds = reinterpret_cast<char *>(smem + L::buf_bytes(m, HAS_SEQ));
-    if (HAS_SEQ)
-        for (int i = tid; i < m * 8; i += BLOCK) reinterpret_cast<double *>(tseq_lds)[i] = a.letter_table[i];
-    const int la = tid * V;
-
-    auto interior = [&](int t) -> bool {
-        const int64_t tile0 = (int64_t)t * L::TILE;
-        const int64_t g0 = tile0 * 7 * (int64_t)sizeof(PROF_T);
-        return (g0 + prof_bytes <= total_bytes) && (!HAS_SEQ || tile0 + code_bytes <= n_pos);
-    };
-
-    int t = blockIdx.x;
-    if (t < n_tiles) stage_tile<V, HAS_SEQ, PROF_T, 0>(a, (int64_t)t * L::TILE, smem, m);
-    __syncthreads();
-#pragma unroll 1
-    for (; t < n_tiles; t += gridDim.x) {
-        const int tn = t + gridDim.x;
-        const bool have_next = tn < n_tiles;
-        const bool pre = have_next && interior(tn);          // workgroup-uniform
-        u32x4 r[MAXCH];
-        u32x4 rc = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < MAXCH; ++i) r[i] = rc;           // defined on both paths: keeps r[] out of scratch
-        if (pre) {
-            const int64_t tile0n = (int64_t)tn * L::TILE;
-            const u32x4 *gsrc = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(a.profile) +
-                                                                tile0n * 7 * (int64_t)sizeof(PROF_T));
-#pragma unroll
-            for (int i = 0; i < MAXCH; ++i) {                 // unconditional, index clamped: keeps r[] in registers
-                const int c = tid + i * BLOCK;
-                r[i] = __builtin_nontemporal_load(gsrc + (c < nch ? c : nch - 1));
-            }
-            if (HAS_SEQ) rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.codes + tile0n) + (tid < ncc ? tid : ncc - 1));
-        }
-        double acc_st[V], acc_sq[V];
-        // opaque copy of the lane's window base: stops hipcc from hoisting the per-lane LDS
-        // addresses of the scoring loop out of the tile loop (they would stay live across the
-        // staging code and push the kernel over the 168-VGPR budget of 3 waves/SIMD)
-        int la_i = la;
-        asm volatile("" : "+v"(la_i));
-        compute_tile<V, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(smem), smem + prof_bytes, tseq_lds,
-                                                 a.struct_pssm, m, la_i, acc_st, acc_sq);
-        emit_tile<V, HAS_SEQ, HITS>(a, (int64_t)t * L::TILE, la_i, acc_st, acc_sq, smem);
-        __syncthreads();                                      // tile (and the output staging) fully consumed
-        if (pre) {
-#pragma unroll
-            for (int i = 0; i < MAXCH; ++i) {
-                const int c = tid + i * BLOCK;
-                if (c < nch) reinterpret_cast<u32x4 *>(smem)[c] = r[i];
-            }
-            if (HAS_SEQ && tid < ncc) reinterpret_cast<u32x4 *>(smem + prof_bytes)[tid] = rc;
-        } else if (have_next) {
-            stage_tile<V, HAS_SEQ, PROF_T, 0>(a, (int64_t)tn * L::TILE, smem, m);
-        }
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -744,77 +616,6 @@ static hipError_t launch_profile_inst(const ScanArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
-static hipError_t launch_pipe_inst(const ScanArgs &a, const Tuning &t, hipStream_t stream)
-{
-    using L = ProfileLayout<V, PROF_T>;
-    const int64_t n_tiles = (a.n_pos + L::TILE - 1) / L::TILE;
-    const int lds = L::total(a.m, HAS_SEQ, 2);
-    auto kern = k_profile_pipe<V, HAS_SEQ, PROF_T, FINITE, HITS>;
-    static int per_cu = 0;              // per instantiation and LDS size class
-    static int per_cu_lds = -1;
-    if (per_cu_lds != lds) {
-        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern));
-        if (e != hipSuccess) return e;
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, (size_t)lds);
-        if (e != hipSuccess) return e;
-        if (nb < 1) return hipErrorInvalidConfiguration;
-        per_cu = nb;
-        per_cu_lds = lds;
-    }
-    int dev = 0, n_cu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    int bpc = per_cu;
-    if (t.blocks_per_cu > 0 && t.blocks_per_cu < bpc) bpc = t.blocks_per_cu;
-    int64_t grid = (int64_t)n_cu * bpc;
-    if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, a, (int)n_tiles);
-    return hipGetLastError();
-}
-
-template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
-static hipError_t launch_stream_inst(const ScanArgs &a, const Tuning &t, hipStream_t stream)
-{
-    using L = ProfileLayout<V, PROF_T>;
-    const int64_t n_tiles = (a.n_pos + L::TILE - 1) / L::TILE;
-    const int lds = L::total(a.m, HAS_SEQ, 1);
-    auto kern = k_profile_stream<V, HAS_SEQ, PROF_T, FINITE, HITS>;
-    static int per_cu = 0;
-    static int per_cu_lds = -1;
-    if (per_cu_lds != lds) {
-        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern));
-        if (e != hipSuccess) return e;
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, (size_t)lds);
-        if (e != hipSuccess) return e;
-        if (nb < 1) return hipErrorInvalidConfiguration;
-        per_cu = nb;
-        per_cu_lds = lds;
-    }
-    int dev = 0, n_cu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    int bpc = per_cu;
-    if (t.blocks_per_cu > 0 && t.blocks_per_cu < bpc) bpc = t.blocks_per_cu;
-    int64_t grid = (int64_t)n_cu * bpc;
-    if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, a, (int)n_tiles);
-    return hipGetLastError();
-}
-
-template <int V, bool HAS_SEQ, typename PROF_T>
-static hipError_t launch_stream_v(const ScanArgs &a, const Tuning &t, hipStream_t stream)
-{
-    if (a.hits) {
-        if (a.struct_finite) return launch_stream_inst<V, HAS_SEQ, PROF_T, true, true>(a, t, stream);
-        return launch_stream_inst<V, HAS_SEQ, PROF_T, false, true>(a, t, stream);
-    }
-    if (a.struct_finite) return launch_stream_inst<V, HAS_SEQ, PROF_T, true, false>(a, t, stream);
-    return launch_stream_inst<V, HAS_SEQ, PROF_T, false, false>(a, t, stream);
-}
-
 template <int V, bool HAS_SEQ, typename PROF_T, int DMA>
 static hipError_t launch_profile_v(const ScanArgs &a, hipStream_t stream)
 {
@@ -826,33 +627,15 @@ static hipError_t launch_profile_v(const ScanArgs &a, hipStream_t stream)
     return launch_profile_inst<V, HAS_SEQ, PROF_T, false, false, DMA>(a, stream);
 }
 
-template <int V, bool HAS_SEQ, typename PROF_T>
-static hipError_t launch_pipe_v(const ScanArgs &a, const Tuning &t, hipStream_t stream)
-{
-    if (a.hits) {
-        if (a.struct_finite) return launch_pipe_inst<V, HAS_SEQ, PROF_T, true, true>(a, t, stream);
-        return launch_pipe_inst<V, HAS_SEQ, PROF_T, false, true>(a, t, stream);
-    }
-    if (a.struct_finite) return launch_pipe_inst<V, HAS_SEQ, PROF_T, true, false>(a, t, stream);
-    return launch_pipe_inst<V, HAS_SEQ, PROF_T, false, false>(a, t, stream);
-}
-
 template <bool HAS_SEQ, typename PROF_T>
 static hipError_t launch_profile_t(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
-    if (t.pipe == 2) return launch_stream_v<5, HAS_SEQ, PROF_T>(a, t, stream);
-    if (t.pipe) {
-        if (t.v == 3) return launch_pipe_v<3, HAS_SEQ, PROF_T>(a, t, stream);
-        if (t.v == 7) return launch_pipe_v<7, HAS_SEQ, PROF_T>(a, t, stream);
-        return launch_pipe_v<5, HAS_SEQ, PROF_T>(a, t, stream);
-    }
     if (t.dma) {
-        if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, 2>(a, stream);
-        return launch_profile_v<7, HAS_SEQ, PROF_T, 2>(a, stream);
+        if (t.v == 7) return launch_profile_v<7, HAS_SEQ, PROF_T, 2>(a, stream);
+        return launch_profile_v<5, HAS_SEQ, PROF_T, 2>(a, stream);
     }
-    if (t.v == 3) return launch_profile_v<3, HAS_SEQ, PROF_T, 0>(a, stream);
-    if (t.v == 5) return launch_profile_v<5, HAS_SEQ, PROF_T, 0>(a, stream);
-    return launch_profile_v<7, HAS_SEQ, PROF_T, 0>(a, stream);
+    if (t.v == 7) return launch_profile_v<7, HAS_SEQ, PROF_T, 0>(a, stream);
+    return launch_profile_v<5, HAS_SEQ, PROF_T, 0>(a, stream);
 }
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what)
@@ -866,7 +649,7 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
         // fp64-stored profile (strict-parity storage): 56 B per position in LDS,
         // so the tile is kept at V = 5 (72 KB, two workgroups per CU).
         Tuning t5 = t;
-        t5.v = (t.pipe ? 3 : 5);
+        t5.v = 5;
         return has_seq ? launch_profile_t<true, double>(a, t5, stream) : launch_profile_t<false, double>(a, t5, stream);
     }
     return has_seq ? launch_profile_t<true, float>(a, t, stream) : launch_profile_t<false, float>(a, t, stream);
