@@ -5,7 +5,9 @@ device is visible, everything here raises.  Nothing under ``oracle/`` is ever
 imported from this package.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -42,6 +44,25 @@ class CapacityError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """A process must hold ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so / libhsa-runtime64.so; if libpfmscan (linked against /opt/rocm) came
+    first, a later ``import torch`` would bring a second HSA runtime and see no GPU.  So
+    when torch is installed its copy of the HIP runtime is loaded first -- by path, without
+    importing torch -- and libpfmscan's NEEDED libamdhip64.so.7 binds to it."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load the shared library (once).  Raises ImportError when it is not built."""
     global _lib
@@ -51,6 +72,7 @@ def load():
         raise ImportError(
             "rnascan_amd: %s is missing -- build it with `python -m rnascan_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
     L.pfmscan_abi_version.restype = i32
