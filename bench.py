@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--width", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-structured", action="store_true",
+                    help="skip the reference-structured Python baseline (B-ref of BASELINE.md section 3)")
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
                     help="c3: seq+struct w=12 (the headline metric); c2: sequence-only PFM (BASELINE configs[1], use --width 8)")
     ap.add_argument("--mode", choices=["scores", "hits"], default="scores",
@@ -253,6 +255,30 @@ def main():
             result["parity_on_sample"] = {"seq_f32_bit_exact": seq_ok, "struct_max_abs_err": st_err,
                                           "struct_within_1e-6": bool(st_err <= 1e-6 and np.array_equal(np.isnan(got_st), np.isnan(ref_st)))}
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+            if not args.no_ref_structured:
+                # B-ref: the reference's own cost structure (per-window Python loop + C call,
+                # pandas iloc + np.dot + nan_to_num, multiprocessing.Pool over records) on a
+                # small sample of the same records, scaled linearly in records (independent)
+                from oracle import ref_structured
+                cores = min(os.cpu_count() or 1, 128)
+                n_seq, n_st = cores * 4, cores
+                lut = np.array(list("ACGU") + ["N"] * 4)
+                seqs, profs = [], []
+                for r in range(n_seq):
+                    c = codes[r * stride: r * stride + args.length].cpu().numpy()
+                    seqs.append("".join(lut[c]))
+                for r in range(n_st):
+                    profs.append(profile[r * stride: r * stride + args.length].cpu().numpy().astype(np.float64))
+                t_seq, t_st, _, _ = ref_structured.time_reference_structured(seqs, profs, table[:, :4].copy(), spssm, 6.0, cores)
+                per_rec = t_seq / n_seq + t_st / n_st          # wall seconds per record with `cores` workers
+                wpr = args.length - args.width + 1
+                result["cpu_baseline_reference_structured"] = {
+                    "value": wpr / per_rec, "unit": "windows/s", "cores": cores, "kind": "port",
+                    "sample": "reference cost model (oracle/ref_structured.py): Pool(%d); sequence side %d records in %.2f s, "
+                              "averaged-structure side %d records in %.2f s, scaled linearly in records"
+                              % (cores, n_seq, t_seq, n_st, t_st),
+                }
+                result["speedup_vs_reference_structured"] = result["value"] / (wpr / per_rec)
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:
