@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-from . import fasta, pack, pssm as pssm_mod, scanner, shard, store
+from . import fasta, pack, pssm as pssm_mod, scanner, shard, store, table
 
 __version__ = "0.10.2+mi355x.1"
 
@@ -263,8 +263,9 @@ def main(argv=None, engine=None, out=None):
                 final = struct_results
 
     if rank == 0:
-        scanner._add_match_id(final)
-        final.to_csv(out, sep="\t", index=False)
+        # Match_ID 1..n after all filtering / joining (rnascan.py:329-332), then the same bytes as
+        # DataFrame.to_csv(sep='\t', index=False) (:559-567), written chunk by chunk
+        table.write_frame(out, final, match_id=True)
     if own_engine:
         engine.close()
     if dist is not None:

@@ -167,3 +167,32 @@ def test_partition_contiguous_balanced():
         loads = [int((L[a:b] + 1).sum()) for a, b in parts]
         assert sum(loads) == int((L + 1).sum())
         assert max(loads) - min(loads) <= 2 * 5001
+
+
+# ---- streaming TSV writer (N3) --------------------------------------------------------
+def test_tsv_writer_matches_pandas_to_csv(golden):
+    import io
+    import pandas as pd
+    from rnascan_amd import table
+    rng = np.random.default_rng(1)
+    n = 5000
+    f32 = np.round(rng.normal(0, 10, n).astype(np.float32), 3)
+    f64 = rng.normal(0, 30, n)
+    f64[:5] = [np.inf, -np.inf, np.nan, 1e-5, -1.7976931348623157e308]
+    f32[5:8] = [np.float32(1e-5), np.float32(123456.789), np.float32(-0.0)]
+    df = pd.DataFrame({"Sequence_ID": ["id%d" % (i // 7) for i in range(n)], "Description": "some text here",
+                       "Motif_ID": "M1", "Start": np.arange(1, n + 1), "End": np.arange(12, n + 12),
+                       "Sequence": ["ACGU"] * n, "LogOdds.Seq": f32, "LogOdds.Struct": f64,
+                       "LogOdds.SeqStruct": f32.astype(np.float64) + f64})
+    want = df.copy()
+    want["Match_ID"] = list(range(1, n + 1))
+    out = io.StringIO()
+    assert table.write_frame(out, df, chunk=777) == n
+    assert out.getvalue() == want.to_csv(sep="\t", index=False)
+    # and on the reference's own captured table
+    g = golden["combine"]
+    gdf = pd.read_csv(io.StringIO(g["tsv"]), sep="\t", dtype={"LogOdds.Seq": np.float32}, keep_default_na=False)
+    gdf["Description.Struct"] = ""
+    out = io.StringIO()
+    table.write_frame(out, gdf.drop(columns="Match_ID"))
+    assert out.getvalue() == g["tsv"]
