@@ -336,13 +336,15 @@ __device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsig
                                              double (&acc_sq)[V])
 {
     double rows[V][7];
-    uint32_t sadr[V];                // LDS byte offset of this slot's letter in table row j0 (advanced per j0 round)
+    uint32_t sadr[V];                // LDS ADDRESS of this slot's letter in table row j0 (advanced per j0 round):
+                                     // ds_read_b64 takes it as is, the row within the round is an immediate offset
+    const uint32_t tbase = lds_addr(tseq_lds);
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         const PROF_T *r = prof_lds + (la + s) * 7;
 #pragma unroll
         for (int k = 0; k < 7; ++k) rows[s][k] = (double)r[k];
-        sadr[s] = HAS_SEQ ? (((uint32_t)code_lds[la + s] & 7u) << 3) : 0u;
+        sadr[s] = HAS_SEQ ? tbase + (((uint32_t)code_lds[la + s] & 7u) << 3) : 0u;
         acc_st[s] = 0.0;
         acc_sq[s] = 0.0;
     }
@@ -378,13 +380,14 @@ __device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsig
                         acc_st[v] += nan_to_num(d);
                     }
                     // table row j = j0 + u: the j0 part lives in sadr, u * 64 is an immediate offset
-                    if (HAS_SEQ) acc_sq[v] += *reinterpret_cast<const double *>(tseq_lds + sadr[slot] + u * 64);
+                    if (HAS_SEQ)
+                        acc_sq[v] += *(const __attribute__((address_space(3))) double *)(uintptr_t)(sadr[slot] + u * 64);
                 }
                 // slot u is dead now: slide in position la + j + V (always staged: tile holds TILE + m rows)
                 const PROF_T *r = prof_lds + (la + j + V) * 7;
 #pragma unroll
                 for (int k = 0; k < 7; ++k) rows[u][k] = (double)r[k];
-                if (HAS_SEQ) sadr[u] = ((((uint32_t)code_lds[la + j + V]) & 7u) << 3) + (uint32_t)j0 * 64u;
+                if (HAS_SEQ) sadr[u] = tbase + ((((uint32_t)code_lds[la + j + V]) & 7u) << 3) + (uint32_t)j0 * 64u;
             }
         }
         if (HAS_SEQ) {
