@@ -48,8 +48,10 @@ constexpr int BLOCK = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int LET_ITERS = 4;                 // k_letters: 4 x 1024 windows per workgroup
-constexpr int LET_TILE = BLOCK * 4 * LET_ITERS;
+// k_letters: a workgroup scores ITERS x 1024 windows (fewer for the widest PFM bucket, whose
+// code registers would otherwise spill)
+__host__ __device__ constexpr int let_iters(int ndw) { return ndw > 9 ? 2 : 4; }
+__host__ __device__ constexpr int let_tile(int ndw) { return BLOCK * 4 * let_iters(ndw); }
 
 // numpy.nan_to_num defaults (rnascan.py:306): NaN -> 0, +-inf -> +-DBL_MAX.
 __device__ __forceinline__ double nan_to_num(double d)
@@ -129,6 +131,8 @@ __device__ __forceinline__ void emit_hits_block(const bool (&pass)[N], const int
 template <int NDW, typename OUT_T, bool HITS>
 __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 {
+    constexpr int LET_ITERS = let_iters(NDW);
+    constexpr int LET_TILE = let_tile(NDW);
     __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
     const int m = a.m;
     for (int i = threadIdx.x; i < m * 8; i += BLOCK) tbl[i] = a.letter_table[i];
@@ -139,31 +143,27 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
     const int ndneed = (m + 2) >> 2;           // highest dword index touched
     OUT_T *__restrict__ out = reinterpret_cast<OUT_T *>(sizeof(OUT_T) == 4 ? (void *)a.out_seq : (void *)a.out_letters_f64);
 
-    bool hpass[4 * LET_ITERS];
-    int64_t hpos[4 * LET_ITERS];
-    float hsq[4 * LET_ITERS];
-    double hst[4 * LET_ITERS];
+    // Three phases per workgroup, so that no wave ever waits for its own stores: (1) every
+    // code load of the 4 x 1024 windows is issued up front, (2) all 16 windows per thread are
+    // scored into registers, (3) the stores go out last and drain after the wave has retired.
+    // (vmcnt counts loads and stores in one in-order queue on gfx950: interleaving
+    // load -> score -> store per 1024 windows made every load wait behind the previous stores,
+    // 0.47 ms on C2 = the SUM of the load-bound and the write-bound time instead of their max.)
+    uint32_t wall[LET_ITERS][NDW];
 #pragma unroll
     for (int it = 0; it < LET_ITERS; ++it) {
         const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
-        const bool live = p0 < n_pos;
-        if (HITS) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                hpass[4 * it + v] = false;
-                hpos[4 * it + v] = p0 + v;
-                hsq[4 * it + v] = 0.f;
-                hst[4 * it + v] = 0.0;
-            }
-        }
-        if (!live) continue;
-        uint32_t w[NDW];
 #pragma unroll
         for (int d = 0; d < NDW; ++d) {
             uint32_t x = 0x07070707u;
-            if (d <= ndneed) x = load_codes4(a.codes, p0 + 4 * d, n_pos);
-            w[d] = (x & 0x07070707u) << 3;      // byte = code * sizeof(double)
+            if (d <= ndneed && !(a.ablate & 2)) x = load_codes4(a.codes, p0 + 4 * d, n_pos);
+            wall[it][d] = (x & 0x07070707u) << 3;      // byte = code * sizeof(double)
         }
+    }
+    double res[LET_ITERS][4];
+#pragma unroll
+    for (int it = 0; it < LET_ITERS; ++it) {
+        const uint32_t (&w)[NDW] = wall[it];
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
@@ -182,37 +182,56 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
                 }
             }
         }
-        if (HITS) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) res[it][v] = acc[v];
+    }
+    if (HITS) {
+        bool hpass[4 * LET_ITERS];
+        int64_t hpos[4 * LET_ITERS];
+        float hsq[4 * LET_ITERS];
+        double hst[4 * LET_ITERS];
+#pragma unroll
+        for (int it = 0; it < LET_ITERS; ++it) {
+            const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float sq = (float)acc[v];
-                const double cmp = sizeof(OUT_T) == 4 ? (double)sq : acc[v];
+                const float sq = (float)res[it][v];
+                const double cmp = sizeof(OUT_T) == 4 ? (double)sq : res[it][v];
+                hpos[4 * it + v] = p0 + v;
                 hpass[4 * it + v] = (p0 + v < n_pos) && (cmp > a.thr_seq);
                 hsq[4 * it + v] = sq;
-                hst[4 * it + v] = acc[v];
+                hst[4 * it + v] = res[it][v];
             }
+        }
+        emit_hits_block<4 * LET_ITERS>(hpass, hpos, hsq, hst, a);
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < LET_ITERS; ++it) {
+        const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
+        if (a.ablate & 4) {
+            if (res[it][0] + res[it][1] + res[it][2] + res[it][3] == 1.2345e300) out[0] = (OUT_T)res[it][0];
         } else if (sizeof(OUT_T) == 4) {
             float *o = reinterpret_cast<float *>(out) + p0;
             if (p0 + 4 <= n_pos) {
-                f32x4 r = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+                f32x4 r = {(float)res[it][0], (float)res[it][1], (float)res[it][2], (float)res[it][3]};
                 __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(o));
             } else {
                 for (int v = 0; v < 4; ++v)
-                    if (p0 + v < n_pos) o[v] = (float)acc[v];
+                    if (p0 + v < n_pos) o[v] = (float)res[it][v];
             }
         } else {
             double *o = reinterpret_cast<double *>(out) + p0;
             if (p0 + 4 <= n_pos) {
-                f64x2 r0 = {acc[0], acc[1]}, r1 = {acc[2], acc[3]};
+                f64x2 r0 = {res[it][0], res[it][1]}, r1 = {res[it][2], res[it][3]};
                 __builtin_nontemporal_store(r0, reinterpret_cast<f64x2 *>(o));
                 __builtin_nontemporal_store(r1, reinterpret_cast<f64x2 *>(o + 2));
             } else {
                 for (int v = 0; v < 4; ++v)
-                    if (p0 + v < n_pos) o[v] = acc[v];
+                    if (p0 + v < n_pos) o[v] = res[it][v];
             }
         }
     }
-    if (HITS) emit_hits_block<4 * LET_ITERS>(hpass, hpos, hsq, hst, a);
 }
 
 // ---------------------------------------------------------------------------
@@ -585,6 +604,7 @@ static hipError_t allow_full_lds(const void *kern)
 template <int NDW>
 static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
 {
+    constexpr int LET_TILE = let_tile(NDW);
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
     if (a.hits)
         hipLaunchKernelGGL((k_letters<NDW, float, true>), dim3(grid), dim3(BLOCK), 0, stream, a);

@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes for the bench kernel (each pass = its own process, counters only).
+# extra bench.py arguments: BENCH_ARGS="--workload c2 --width 8"
 # usage: tools/pmc.sh <tag> ["ENV=.. ENV=.."] ; output: gpurun_out/pmc_<tag>/pass*/ + summary
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -16,6 +17,6 @@ for counters in \
   "FETCH_SIZE" \
   "WRITE_SIZE" ; do
   i=$((i+1))
-  rocprofv3 --pmc $counters --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; }
+  rocprofv3 --pmc $counters --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; }
 done
 python3 $ROOT/tools/pmc_summary.py $OUT | tee $OUT/summary.txt
