@@ -58,3 +58,10 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert not pat.search(src), "%s reaches into oracle/" % f
+
+
+def test_header_is_plain_c():
+    """include/pfmscan.h and its C consumer compile as C99 (no C++ in the boundary)"""
+    import subprocess
+    src = os.path.join(REPO, "tests", "c", "abi_smoke.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(REPO, "include"), src])

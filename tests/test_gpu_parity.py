@@ -258,3 +258,18 @@ def test_no_window_spans_two_records(ctx):
     mask = s.window_mask(m)
     assert np.isnan(got[~mask]).all()
     assert not np.isnan(got[mask]).any()
+
+
+def test_c_program_through_the_abi(tmp_path):
+    """a plain-C program linked against libpfmscan.so (no Python, no torch in the process)"""
+    import os
+    import subprocess
+    from conftest import REPO
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(REPO, "rnascan_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(REPO, "include"),
+                           os.path.join(REPO, "tests", "c", "abi_smoke.c"), "-o", exe,
+                           "-L", libdir, "-l:libpfmscan.so", "-lm", "-Wl,-rpath," + libdir + ":/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("OK")
