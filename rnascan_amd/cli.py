@@ -17,7 +17,7 @@ import numpy as np
 
 from . import fasta, pack, pssm as pssm_mod, scanner, shard, store, table
 
-__version__ = "0.10.2+mi355x.1"
+from . import __version__
 
 
 def getoptions(argv=None):
