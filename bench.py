@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--variant", choices=["finite", "inf"], default="finite",
                     help="finite: pseudocount 0.01 PSSMs (headline); inf: pseudocount 0 PSSMs with -inf cells, profile with "
                          "exact zeros and 0.1 %% foreign letters (exercises nan_to_num / NaN windows at full size)")
-    ap.add_argument("--mode", choices=["scores", "hits"], default="scores",
-                    help="scores: all-scores (the headline, 41.1 B/window); hits: thresholded hits (29.1 B/window + 20 B/hit)")
+    ap.add_argument("--mode", choices=["scores", "hits", "hits2"], default="scores",
+                    help="scores: all-scores (the headline, 41.1 B/window); hits: thresholded hits, one fused pass "
+                         "(29.1 B/window + 20 B/hit); hits2: candidate-then-verify (letters pass, structure only at its hits)")
     ap.add_argument("--minscore", type=float, default=6.0, help="threshold of --mode hits (seq > m and struct > m)")
     args = ap.parse_args()
 
@@ -144,16 +145,16 @@ def main():
     assert stream != 0
 
     cap = 1 << 24
-    if args.mode == "hits":
+    if args.mode in ("hits", "hits2"):
         hit_pos = torch.empty(cap, dtype=torch.int64, device=dev)
         hit_seq = torch.empty(cap, dtype=torch.float32, device=dev)
         hit_st = torch.empty(cap, dtype=torch.float64, device=dev)
         hit_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
-        if args.mode == "hits":
+        if args.mode in ("hits", "hits2"):
             hit_count.zero_()
-            ctx.hits_dev(motif, codes.data_ptr(), None if seq_only else profile.data_ptr(),
+            (ctx.hits_dev if args.mode == "hits" else ctx.hits_adaptive_dev)(motif, codes.data_ptr(), None if seq_only else profile.data_ptr(),
                          _lib.PROFILE_NONE if seq_only else _lib.PROFILE_F32, n_pos, args.minscore,
                          args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
                          hit_count.data_ptr(), stream)
@@ -194,7 +195,7 @@ def main():
         in_b, out_b, hit_b = (1, 4, 12) if seq_only else (29, 12, 20)
         alg_bytes = args.records * args.length * in_b + windows * out_b      # per launch, per GPU
         n_hits = None
-        if args.mode == "hits":
+        if args.mode != "scores":
             n_hits = int(hit_count.item())
             alg_bytes = args.records * args.length * in_b + min(n_hits, cap) * hit_b
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9

@@ -143,6 +143,19 @@ int pfmscan_hits_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                      float *d_hit_seq, double *d_hit_struct,
                      uint64_t *d_hit_count, void *stream);
 
+/* Same contract and arguments as pfmscan_hits_dev, but SYNCHRONISES `stream` and may take
+ * two passes: when the motif has both parts and thr_seq is finite, the letters kernel
+ * (1 byte per position) runs over everything and the structure score is computed only at
+ * its hits (k_struct_at), because a combined hit needs BOTH thresholds (rnascan.py:422-433)
+ * and the letter side is selective at real thresholds.  Falls back to the fused pass when
+ * more than 1/16 of the windows pass the letter threshold.  Same hits, same scores. */
+int pfmscan_hits_adaptive_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                              const uint8_t *d_codes, const void *d_profile,
+                              int profile_dtype, int64_t n_pos, double thr_seq,
+                              double thr_struct, int64_t capacity, int64_t *d_hit_pos,
+                              float *d_hit_seq, double *d_hit_struct,
+                              uint64_t *d_hit_count, void *stream);
+
 /* ---- host-buffer forms ------------------------------------------------------
  * Same contracts with HOST pointers: the ctx stages H2D into its own device
  * scratch, launches, copies back and synchronises. */

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pfmscan_device_info", "pfmscan_synchronize", "pfmscan_motif_create", "pfmscan_motif_destroy",
     "pfmscan_pwm_calculate", "pfmscan_scan_dev", "pfmscan_scan_letters_f64_dev", "pfmscan_hits_dev",
     "pfmscan_scan_host", "pfmscan_scan_letters_f64_host", "pfmscan_hits_host", "pfmscan_time_scan_dev",
-    "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged",
+    "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
 ]
 
 
@@ -90,6 +90,7 @@ def load():
     L.pfmscan_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp]
     L.pfmscan_scan_letters_f64_dev.argtypes = [vp, vp, vp, i64, vp, vp]
     L.pfmscan_hits_dev.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, vp, vp]
+    L.pfmscan_hits_adaptive_dev.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, vp, vp]
     L.pfmscan_scan_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp]
     L.pfmscan_scan_letters_f64_host.argtypes = [vp, vp, vp, i64, vp]
     L.pfmscan_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
@@ -298,6 +299,14 @@ class Context(object):
                                              int(n_pos), float(thr_seq), float(thr_struct), int(capacity),
                                              _ptr(d_hit_pos), _ptr(d_hit_seq), _ptr(d_hit_struct), _ptr(d_hit_count),
                                              _ptr(stream)))
+
+    def hits_adaptive_dev(self, motif, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity,
+                          d_hit_pos, d_hit_seq, d_hit_struct, d_hit_count, stream=None):
+        """hits_dev that may run candidate-then-verify (synchronises the stream)"""
+        self._check(self._L.pfmscan_hits_adaptive_dev(self._h, motif._h, _ptr(d_codes), _ptr(d_profile),
+                                                      int(profile_dtype), int(n_pos), float(thr_seq), float(thr_struct),
+                                                      int(capacity), _ptr(d_hit_pos), _ptr(d_hit_seq), _ptr(d_hit_struct),
+                                                      _ptr(d_hit_count), _ptr(stream)))
 
     def time_scan_dev(self, motif, d_codes, d_profile, profile_dtype, n_pos, d_out_seq, d_out_struct,
                       stream=None, warmup=1, iters=5):

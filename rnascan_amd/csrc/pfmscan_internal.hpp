@@ -38,8 +38,15 @@ struct Tuning {
     int dma = 1;            // k_profile: stage the tile with LDS-DMA (global_load_lds, 2.34 ms on C3) instead of
                             // through registers (2.51 ms)
     int ablate = 0;         // see ScanArgs::ablate; results are WRONG when non-zero
+    int two_phase = 1;      // combined hits through the host/staged API: letters first, structure only at candidates
 };
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);
+
+// Second phase of the candidate-then-verify combined scan: structure score of the windows
+// listed in cand_pos[0 .. min(*cand_count, cand_cap)) (hits of a letters-only pass, whose
+// float32 scores are cand_seq), kept when > a.thr_struct and appended to a.hit_*.
+hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
+                            const unsigned long long *cand_count, int64_t cand_cap, hipStream_t stream);
 
 }  // namespace pfmscan
