@@ -36,16 +36,16 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def make_pssms(width, variant="finite"):
+def make_pssms(width, variant="finite", seed=0):
     """Seeded PFMs -> log-odds operands: rows ~ Dirichlet(0.5), uniform background.
     variant "finite": pseudocount 0.01 (every log-odds finite; SURVEY 8d C3 headline);
     variant "inf": pseudocount 0 with 15 % of the cells zeroed (-inf log-odds, the
     nan_to_num path of rnascan.py:306 becomes first-order behaviour)."""
     from rnascan_amd import pssm, pack
     from collections import OrderedDict
-    rs = np.random.RandomState(11)
+    rs = np.random.RandomState(11 + seed)
     seq_counts = rs.dirichlet(np.full(4, 0.5), size=width)
-    rs = np.random.RandomState(13)
+    rs = np.random.RandomState(13 + seed)
     st_counts = rs.dirichlet(np.full(7, 0.5), size=width)
     pc = 0.01
     if variant == "inf":
@@ -98,8 +98,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-structured", action="store_true",
                     help="skip the reference-structured Python baseline (B-ref of BASELINE.md section 3)")
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
-                    help="c3: seq+struct w=12 (the headline metric); c2: sequence-only PFM (BASELINE configs[1], use --width 8)")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+                    help="c3: seq+struct w=12 (the headline metric); c2: sequence-only PFM (BASELINE configs[1], use --width 8); "
+                         "c5: a library of --motifs seq+struct PFM pairs over the same resident records, hits mode "
+                         "(BASELINE configs[4]); value is then window x motif pairs per second")
+    ap.add_argument("--motifs", type=int, default=256, help="PFM pairs of --workload c5")
     ap.add_argument("--variant", choices=["finite", "inf"], default="finite",
                     help="finite: pseudocount 0.01 PSSMs (headline); inf: pseudocount 0 PSSMs with -inf cells, profile with "
                          "exact zeros and 0.1 %% foreign letters (exercises nan_to_num / NaN windows at full size)")
@@ -128,6 +131,12 @@ def main():
     table, spssm = make_pssms(args.width, args.variant)
     seq_only = args.workload == "c2"
     motif = ctx.motif(table, None if seq_only else spssm)
+    library = []
+    if args.workload == "c5":
+        args.mode = "hits2"
+        for k in range(args.motifs):                      # seeds 1000 + k
+            t_k, s_k = make_pssms(args.width, args.variant, seed=1000 + k)
+            library.append(ctx.motif(t_k, s_k))
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank,
                                         foreign=0.001 if args.variant == "inf" else 0.0,
                                         zero_snap=args.variant == "inf")
@@ -152,6 +161,13 @@ def main():
         hit_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
+        if library:
+            for mo in library:
+                hit_count.zero_()
+                ctx.hits_adaptive_dev(mo, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, args.minscore,
+                                      args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
+                                      hit_count.data_ptr(), stream)
+            return
         if args.mode in ("hits", "hits2"):
             hit_count.zero_()
             (ctx.hits_dev if args.mode == "hits" else ctx.hits_adaptive_dev)(motif, codes.data_ptr(), None if seq_only else profile.data_ptr(),
@@ -191,7 +207,7 @@ def main():
 
     result = None
     if rank == 0:
-        total_windows = windows * world * args.steps
+        total_windows = windows * world * args.steps * (len(library) if library else 1)
         in_b, out_b, hit_b = (1, 4, 12) if seq_only else (29, 12, 20)
         alg_bytes = args.records * args.length * in_b + windows * out_b      # per launch, per GPU
         n_hits = None
@@ -209,9 +225,10 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "scored windows/sec (%s, w=%d)" % ("seq-only" if seq_only else "seq+struct", args.width),
+            "metric": ("scored window x motif pairs/sec (%d-PFM library, seq+struct, w=%d)" % (len(library), args.width)) if library
+                      else "scored windows/sec (%s, w=%d)" % ("seq-only" if seq_only else "seq+struct", args.width),
             "value": total_windows / elapsed,
-            "unit": "windows/s",
+            "unit": "window-motif pairs/s" if library else "windows/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -222,7 +239,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes"
+                "workload": ("C5: library of %d seq+struct PFM pairs (width %d) x %d synthetic records x %d nt per GPU, "
+                             "resident stream, thresholded hits per motif (candidate-then-verify)"
+                             % (len(library), args.width, args.records, args.length)) if library else
+                            ("C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes"
                              % (args.records, args.length, args.width)) if seq_only else
                             ("C3: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, "
                              "uint8 codes + float32 [n][7] profile, all-scores (f32 seq + f64 struct per window)"
