@@ -131,11 +131,14 @@ __device__ __forceinline__ void emit_hits_block(const uint32_t passmask, PosF po
 // bytes 0 .. m+2 relative to its first window -> NDW = 5 / 9 / 17 for
 // m <= 16 / 32 / 64.  OUT_T = float (_pwm.c) or double (matrix.py:25-43).
 // ---------------------------------------------------------------------------
-template <int NDW, typename OUT_T, bool HITS>
+template <int NDW, typename OUT_T, bool HITS, int W>
 __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 {
-    constexpr int LET_ITERS = let_iters(NDW);
+    // W consecutive windows per thread and round (4: one 16-byte store per round; 8: fewer code
+    // loads and byte extractions per window, used where nothing is stored), 16 windows per thread
+    constexpr int ROUNDS = (let_iters(NDW) * 4) / W;
     constexpr int LET_TILE = let_tile(NDW);
+    constexpr int NW = NDW + (W - 4) / 4;              // code dwords per round: bytes 0 .. W + m - 2
     __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
     const int m = a.m;
     for (int i = threadIdx.x; i < m * 8; i += BLOCK) tbl[i] = a.letter_table[i];
@@ -143,31 +146,33 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 
     const int64_t n_pos = a.n_pos;
     const int64_t tile0 = (int64_t)blockIdx.x * LET_TILE;
-    const int ndneed = (m + 2) >> 2;           // highest dword index touched
+    const int ndneed = (W + m - 2) >> 2;               // highest dword index touched
     OUT_T *__restrict__ out = reinterpret_cast<OUT_T *>(sizeof(OUT_T) == 4 ? (void *)a.out_seq : (void *)a.out_letters_f64);
 
     // Three phases per workgroup, so that no wave ever waits for its own stores: (1) every
-    // code load of the 4 x 1024 windows is issued up front, (2) all 16 windows per thread are
+    // code load of the workgroup's windows is issued up front, (2) all 16 windows per thread are
     // scored into registers, (3) the stores go out last and drain after the wave has retired.
     // (vmcnt counts loads and stores in one in-order queue on gfx950: interleaving
     // load -> score -> store per 1024 windows made every load wait behind the previous stores,
     // 0.47 ms on C2 = the SUM of the load-bound and the write-bound time instead of their max.)
-    uint32_t wall[LET_ITERS][NDW];
+    uint32_t wall[ROUNDS][NW];
 #pragma unroll
-    for (int it = 0; it < LET_ITERS; ++it) {
-        const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
+    for (int it = 0; it < ROUNDS; ++it) {
+        const int64_t p0 = tile0 + (int64_t)it * (BLOCK * W) + (int64_t)threadIdx.x * W;
 #pragma unroll
-        for (int d = 0; d < NDW; ++d) {
+        for (int d = 0; d < NW; ++d) {
             uint32_t x = 0x07070707u;
             if (d <= ndneed && !(a.ablate & 2)) x = load_codes4(a.codes, p0 + 4 * d, n_pos);
             wall[it][d] = (x & 0x07070707u) << 3;      // byte = code * sizeof(double)
         }
     }
-    double res[LET_ITERS][4];
+    double res[ROUNDS][W];
 #pragma unroll
-    for (int it = 0; it < LET_ITERS; ++it) {
-        const uint32_t (&w)[NDW] = wall[it];
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < ROUNDS; ++it) {
+        const uint32_t (&w)[NW] = wall[it];
+        double acc[W];
+#pragma unroll
+        for (int v = 0; v < W; ++v) acc[v] = 0.0;
 #pragma unroll
         for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
             if (j0 >= m) break;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
                 if (j < m) {
                     const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < W; ++v) {
                         const int q = j + v;    // byte index relative to p0, compile-time
                         const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
                         acc[v] += *reinterpret_cast<const double *>(row + b);
@@ -186,51 +191,55 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
             }
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) res[it][v] = acc[v];
+        for (int v = 0; v < W; ++v) res[it][v] = acc[v];
     }
     if (HITS) {
         uint32_t mask = 0;
-        const int64_t pbase = tile0 + (int64_t)threadIdx.x * 4;
+        const int64_t pbase = tile0 + (int64_t)threadIdx.x * W;
 #pragma unroll
-        for (int it = 0; it < LET_ITERS; ++it) {
+        for (int it = 0; it < ROUNDS; ++it) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < W; ++v) {
                 const double cmp = sizeof(OUT_T) == 4 ? (double)(float)res[it][v] : res[it][v];
-                if ((pbase + it * (BLOCK * 4) + v < n_pos) && (cmp > a.thr_seq)) mask |= 1u << (4 * it + v);
+                if ((pbase + it * (BLOCK * W) + v < n_pos) && (cmp > a.thr_seq)) mask |= 1u << (W * it + v);
             }
         }
         if (a.ablate & 8) {                 // timing diagnostic: no hit emission at all
             if (mask == 0xdeadbeefu) a.hit_pos[0] = pbase;
             return;
         }
-        emit_hits_block<4 * LET_ITERS>(
-            mask, [&](int i) { return pbase + (int64_t)(i >> 2) * (BLOCK * 4) + (i & 3); },
-            [&](int i) { return (float)res[i >> 2][i & 3]; }, [&](int i) { return res[i >> 2][i & 3]; }, a);
+        emit_hits_block<ROUNDS * W>(
+            mask, [&](int i) { return pbase + (int64_t)(i / W) * (BLOCK * W) + (i % W); },
+            [&](int i) { return (float)res[i / W][i % W]; }, [&](int i) { return res[i / W][i % W]; }, a);
         return;
     }
 #pragma unroll
-    for (int it = 0; it < LET_ITERS; ++it) {
-        const int64_t p0 = tile0 + (int64_t)it * (BLOCK * 4) + (int64_t)threadIdx.x * 4;
-        if (a.ablate & 4) {
-            if (res[it][0] + res[it][1] + res[it][2] + res[it][3] == 1.2345e300) out[0] = (OUT_T)res[it][0];
-        } else if (sizeof(OUT_T) == 4) {
-            float *o = reinterpret_cast<float *>(out) + p0;
-            if (p0 + 4 <= n_pos) {
-                f32x4 r = {(float)res[it][0], (float)res[it][1], (float)res[it][2], (float)res[it][3]};
-                __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(o));
+    for (int it = 0; it < ROUNDS; ++it) {
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h) {
+            const int64_t p0 = tile0 + (int64_t)it * (BLOCK * W) + (int64_t)threadIdx.x * W + 4 * h;
+            const double *r4 = &res[it][4 * h];
+            if (a.ablate & 4) {
+                if (r4[0] + r4[1] + r4[2] + r4[3] == 1.2345e300) out[0] = (OUT_T)r4[0];
+            } else if (sizeof(OUT_T) == 4) {
+                float *o = reinterpret_cast<float *>(out) + p0;
+                if (p0 + 4 <= n_pos) {
+                    f32x4 r = {(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+                    __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(o));
+                } else {
+                    for (int v = 0; v < 4; ++v)
+                        if (p0 + v < n_pos) o[v] = (float)r4[v];
+                }
             } else {
-                for (int v = 0; v < 4; ++v)
-                    if (p0 + v < n_pos) o[v] = (float)res[it][v];
-            }
-        } else {
-            double *o = reinterpret_cast<double *>(out) + p0;
-            if (p0 + 4 <= n_pos) {
-                f64x2 r0 = {res[it][0], res[it][1]}, r1 = {res[it][2], res[it][3]};
-                __builtin_nontemporal_store(r0, reinterpret_cast<f64x2 *>(o));
-                __builtin_nontemporal_store(r1, reinterpret_cast<f64x2 *>(o + 2));
-            } else {
-                for (int v = 0; v < 4; ++v)
-                    if (p0 + v < n_pos) o[v] = res[it][v];
+                double *o = reinterpret_cast<double *>(out) + p0;
+                if (p0 + 4 <= n_pos) {
+                    f64x2 r0 = {r4[0], r4[1]}, r1 = {r4[2], r4[3]};
+                    __builtin_nontemporal_store(r0, reinterpret_cast<f64x2 *>(o));
+                    __builtin_nontemporal_store(r1, reinterpret_cast<f64x2 *>(o + 2));
+                } else {
+                    for (int v = 0; v < 4; ++v)
+                        if (p0 + v < n_pos) o[v] = r4[v];
+                }
             }
         }
     }
@@ -669,12 +678,14 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
 {
     constexpr int LET_TILE = let_tile(NDW);
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
+    // hits: 8 windows per thread (0.39 vs 0.49 ms on C2 w=12); scores: 4, so that every store instruction
+    // writes 1 KiB contiguous (8 per thread measured 0.56 vs 0.41 ms)
     if (a.hits)
-        hipLaunchKernelGGL((k_letters<NDW, float, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_letters<NDW, float, true, 8>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else if (a.out_letters_f64)
-        hipLaunchKernelGGL((k_letters<NDW, double, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_letters<NDW, double, false, 4>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else
-        hipLaunchKernelGGL((k_letters<NDW, float, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_letters<NDW, float, false, 4>), dim3(grid), dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 
