@@ -2,34 +2,38 @@
 // PFM scanner.  wave64, 256-thread workgroups, fp64 accumulation, no MFMA (the
 // contraction is width x alphabet -- far below one MFMA tile); the design goal
 // is HBM streaming: every input byte is read once with 16-byte-per-lane
-// coalesced loads, every output byte written once with 16-byte-per-lane stores.
+// coalesced accesses, every output byte written once with 16-byte-per-lane stores.
 //
-// Two kernel families:
+// Kernels (DESIGN.md section 5 has the measurements behind each choice):
 //
-//  k_letters   codes only (config 2, and the letter-string structure scan).
-//              A thread owns 4 consecutive windows; it loads its own 4 code
-//              bytes plus the (m-1)-byte halo as dwords straight from global
-//              (lane stride 4 B -> one 256-B line pair per wave-instruction),
-//              looks each letter up in an LDS copy of the [m][8] log-odds table
-//              (ds_read_b64, all lanes of an instruction hit the SAME table
-//              row -> at most 8 distinct addresses on 16 distinct banks, no
-//              conflict) and writes its 4 float32 scores as ONE 16-byte store,
-//              so a wave-instruction writes 1 KiB contiguous.
+//  k_letters   codes only (config 2, the letter-string structure scan, and the
+//              first pass of the combined hits scan).  A thread owns W = 4 (scores)
+//              or 8 (hits) consecutive windows per round; it loads its code bytes
+//              plus the (m-1)-byte halo as dwords straight from global, looks each
+//              letter up in an LDS copy of the [m][8] log-odds table (ds_read_b64;
+//              all lanes of an instruction hit the SAME table row -> at most 8
+//              distinct addresses on 16 distinct banks, no conflict) and writes 4
+//              float32 scores as ONE 16-byte store, so a wave-instruction writes
+//              1 KiB contiguous.  All loads first, all stores last (vmcnt is one
+//              in-order queue for loads and stores).
 //
 //  k_profile   codes + averaged-structure profile (config 3, the headline).
-//              A workgroup stages one tile of T = 256*V positions (+ m-1 halo)
-//              of the [n_pos][7] profile through LDS with 16-byte coalesced
-//              loads, then each thread scores V consecutive windows.  V is ODD
-//              so the per-lane LDS row stride (7*V dwords) is odd and the
-//              row reads are bank-conflict free on the linear (DMA-compatible)
-//              image.  The window sum over j is SEQUENTIAL in one lane (fp64),
-//              exactly like the reference loops, so float32 sequence scores are
-//              bit-exact; lanes cooperate on loading, never on the sum.
-//              The thread keeps a sliding window of V profile rows (fp64) in
-//              registers; step j multiplies all V rows by PSSM row j (uniform,
-//              scalar-loaded) and loads ONE new row, so a row is converted
-//              fp32->fp64 once per thread and PSSM rows are read once per step.
-//              Scores leave through an LDS transpose as 16-byte stores.
+//              A workgroup stages one tile of T = 256*V positions (+ m halo rows)
+//              of the [n_pos][7] profile into LDS with LDS-DMA (global_load_lds,
+//              1 KiB lane-linear pieces), then each thread scores V consecutive
+//              windows.  V is ODD so the per-lane LDS row stride (7*V dwords) is
+//              odd and the row reads are bank-conflict free on the linear image.
+//              The window sum over j is SEQUENTIAL in one lane (fp64), exactly like
+//              the reference loops, so float32 sequence scores are bit-exact; lanes
+//              cooperate on loading, never on the sum.  The thread keeps a sliding
+//              window of V profile rows (fp64) in registers; step j multiplies all
+//              V rows by PSSM row j (uniform, s_load'ed, SGPR operand of v_fmac_f64)
+//              and slides in ONE new row, so a row is converted fp32->fp64 once per
+//              thread.  Scores leave through a wave-private LDS transpose as
+//              16-byte nontemporal stores.
+//
+//  k_struct_at structure score at a list of candidate windows (second pass of the
+//              candidate-then-verify combined hits scan).
 //
 // Reference semantics restated here (upstream paths, v0.10.2):
 //   _pwm.c:34-68       score = 0.0 (double); score += M[j][col]; (float)score;
