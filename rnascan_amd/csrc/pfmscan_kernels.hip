@@ -54,7 +54,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 // k_letters: a workgroup scores ITERS x 1024 windows (fewer for the widest PFM bucket, whose
 // code registers would otherwise spill)
-__host__ __device__ constexpr int let_iters(int ndw) { return ndw > 9 ? 2 : 4; }
+__host__ __device__ constexpr int let_iters(int ndw) { return ndw > 9 ? 2 : 4; }   // 8 rounds measured slower (occupancy 5)
 __host__ __device__ constexpr int let_tile(int ndw) { return BLOCK * 4 * let_iters(ndw); }
 
 // numpy.nan_to_num defaults (rnascan.py:306): NaN -> 0, +-inf -> +-DBL_MAX.
@@ -215,6 +215,39 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
         emit_hits_block<ROUNDS * W>(
             mask, [&](int i) { return pbase + (int64_t)(i / W) * (BLOCK * W) + (i % W); },
             [&](int i) { return (float)res[i / W][i % W]; }, [&](int i) { return res[i / W][i % W]; }, a);
+        return;
+    }
+    if (W == 8 && sizeof(OUT_T) == 4 && !(a.ablate & 4)) {
+        // 8 windows per thread: transpose through a wave-private LDS strip so that every store
+        // instruction still writes 1 KiB contiguous (LDS operations of one wave execute in order)
+        __shared__ __align__(16) float strip[BLOCK / 64][64 * 8];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float *mine = strip[wave];
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            f32x4 lo = {(float)res[it][0], (float)res[it][1], (float)res[it][2], (float)res[it][3]};
+            f32x4 hi = {(float)res[it][4], (float)res[it][5], (float)res[it][6], (float)res[it][7]};
+            reinterpret_cast<f32x4 *>(mine)[2 * lane] = lo;
+            reinterpret_cast<f32x4 *>(mine)[2 * lane + 1] = hi;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int64_t w0 = tile0 + (int64_t)it * (BLOCK * 8) + (int64_t)wave * 512;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = lane + 64 * k;
+                const int64_t p = w0 + 4 * (int64_t)c;
+                float *o = reinterpret_cast<float *>(out) + p;
+                if (p + 4 <= n_pos) {
+                    __builtin_nontemporal_store(reinterpret_cast<const f32x4 *>(mine)[c], reinterpret_cast<f32x4 *>(o));
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (p + e < n_pos) o[e] = mine[4 * c + e];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         return;
     }
 #pragma unroll
@@ -682,14 +715,14 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
 {
     constexpr int LET_TILE = let_tile(NDW);
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
-    // hits: 8 windows per thread (0.39 vs 0.49 ms on C2 w=12); scores: 4, so that every store instruction
-    // writes 1 KiB contiguous (8 per thread measured 0.56 vs 0.41 ms)
+    // 8 windows per thread (hits: 0.39 vs 0.49 ms on C2 w=12; scores, with the LDS transpose that keeps
+    // the stores 1 KiB contiguous: 0.39 vs 0.42 ms on C2 w=8; without the transpose 0.56 ms)
     if (a.hits)
         hipLaunchKernelGGL((k_letters<NDW, float, true, 8>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else if (a.out_letters_f64)
         hipLaunchKernelGGL((k_letters<NDW, double, false, 4>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else
-        hipLaunchKernelGGL((k_letters<NDW, float, false, 4>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_letters<NDW, float, false, 8>), dim3(grid), dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 
