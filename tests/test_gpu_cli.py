@@ -144,3 +144,41 @@ def test_staged_api_matches_host_api(ctx, oracle):
         only_seq = ctx.motif(letter_table=rand_table(rng, 4))
         ctx.stage(None, s.profile)
         ctx.hits_staged(only_seq, 0.0, 0.0)
+
+
+def _gpu_cli_worker(rank, world, port, outdir, argv):
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RNASCAN_DIST_BACKEND": "gloo"})
+    from rnascan_amd import cli
+    with open(os.path.join(outdir, "out.%d.tsv" % rank), "w") as out:
+        cli.main(argv, out=out)                     # real HipEngine, one ctx per process
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_cli_two_processes_one_gpu(tmp_path):
+    """the sharded product path with the REAL engine: two ranks (gloo rendezvous, both on GPU 0 because
+    the box has one), each scanning its contiguous share of the records; rank 0 prints the whole table"""
+    import socket
+    import torch.multiprocessing as mp
+    from rnascan_amd import cli
+    rng = np.random.default_rng(9)
+    fa = tmp_path / "many.fa"
+    with open(fa, "w") as f:
+        for i in range(200):
+            f.write(">rec%d d%d\n%s\n" % (i, i, "".join(rng.choice(list("ACGTN"), size=int(rng.integers(0, 3000)),
+                                                                     p=[.245, .245, .245, .245, .02]))))
+    argv = ["-p", SEQ_PFM, "-C", "0.01", "-m", "2", str(fa)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gpu_cli_worker, args=(2, port, str(tmp_path), argv), nprocs=2, join=True)
+    single = io.StringIO()
+    cli.main(argv, out=single)
+    assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
+    assert open(tmp_path / "out.1.tsv").read() == ""
+    assert single.getvalue().count("\n") > 50
