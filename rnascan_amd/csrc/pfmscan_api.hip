@@ -35,6 +35,8 @@ struct pfmscan_ctx {
     int64_t staged_n = -1;
     int staged_dtype = PFMSCAN_PROFILE_NONE;
     bool staged_codes = false, staged_profile = false;
+    // candidate-then-verify: the last full letters pass was selective -> skip the pilot next time
+    bool two_phase_hot = false;
 };
 
 struct pfmscan_motif {
@@ -376,18 +378,27 @@ static int hits_core(pfmscan_ctx *ctx, const pfmscan_motif *mo, const ScanArgs &
     };
     uint64_t n_cand = 0, worst = 0;
     const int64_t pilot_n = std::max<int64_t>((int64_t)1 << 22, n_pos / 64);
-    if (pilot_n < n_pos) {
+    if (pilot_n < n_pos && !ctx->two_phase_hot) {
         ScanArgs ap = a1;
         ap.n_pos = pilot_n;
         HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, counter_bytes, st));
         if ((rc = do_launch(ctx, ap, st))) return rc;
         if ((rc = read_counts(n_cand, worst))) return rc;
-        if ((int64_t)n_cand * 32 > pilot_n) return do_launch(ctx, fused, st);      // not selective: one fused pass
+        if ((int64_t)n_cand * 32 > pilot_n) {                                      // not selective: one fused pass
+            ctx->two_phase_hot = false;
+            return do_launch(ctx, fused, st);
+        }
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, counter_bytes, st));
     if ((rc = do_launch(ctx, a1, st))) return rc;
     if ((rc = read_counts(n_cand, worst))) return rc;
-    if ((int64_t)worst > cand_shard_cap) return do_launch(ctx, fused, st);         // pilot under-estimated
+    if ((int64_t)worst > cand_shard_cap) {                                          // pilot under-estimated
+        ctx->two_phase_hot = false;
+        return do_launch(ctx, fused, st);
+    }
+    // a library scan calls this once per motif with similar selectivity: skip the pilot while the letters
+    // pass keeps coming back well under the candidate capacity
+    ctx->two_phase_hot = (int64_t)n_cand * 4 < cand_cap;
     if (n_cand == 0) return PFMSCAN_OK;
     // phase 2: structure score at the candidates only
     hipError_t e = launch_struct_at(fused, (const int64_t *)ctx->cand_pos.p, (const float *)ctx->cand_seq.p,
