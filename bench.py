@@ -90,7 +90,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)   # the first ~10 launches after data generation run 5-30 % slow (clock ramp)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=int, default=15,
+                    help="untimed launches right after data generation, BEFORE the --warmup steps: the chip's clocks "
+                         "take ~10 launches to settle after the generation kernels (per-dispatch times ramp 3.1 -> 2.3 ms)")
     ap.add_argument("--records", type=int, default=100000, help="records per GPU")
     ap.add_argument("--length", type=int, default=3000)
     ap.add_argument("--width", type=int, default=12)
@@ -184,6 +187,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    for _ in range(args.settle if not library else 0):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -248,7 +253,7 @@ def main():
                              "uint8 codes + float32 [n][7] profile, all-scores (f32 seq + f64 struct per window)"
                              % (args.records, args.length, args.width)),
                 "records_per_gpu": args.records, "record_length": args.length, "pfm_width": args.width,
-                "variant": args.variant, "windows_per_gpu_per_step": windows, "mode": "all-scores" if args.mode == "scores" else "hits",
+                "variant": args.variant, "settle_launches": args.settle, "windows_per_gpu_per_step": windows, "mode": "all-scores" if args.mode == "scores" else "hits",
                 "minscore": None if args.mode == "scores" else args.minscore, "hits_per_step": n_hits,
                 "sharding": "records, no collective",
             },
