@@ -669,10 +669,22 @@ __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int
         const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(a.profile) + p * 7;
         const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)a.struct_pssm;
         for (int j = 0; j < a.m; ++j) {
+            // one row = 7 contiguous values at element alignment: 16 + 8 + 4 bytes (or 2 x 16 + 16 + 8 for
+            // fp64) instead of 7 scalar loads -- the candidates are scattered, so this pass is bound by the
+            // number of vector-memory instructions, not by bytes
+            typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+            typedef PROF_T v2_t __attribute__((ext_vector_type(2), aligned(sizeof(PROF_T))));
             const PROF_T *r = prof + j * 7;
-            double d = (double)r[0] * pssm[j * 7];
-#pragma unroll
-            for (int k = 1; k < 7; ++k) d = fma((double)r[k], pssm[j * 7 + k], d);
+            const v4_t r03 = *reinterpret_cast<const v4_t *>(r);
+            const v2_t r45 = *reinterpret_cast<const v2_t *>(r + 4);
+            const PROF_T r6 = r[6];
+            double d = (double)r03[0] * pssm[j * 7];
+            d = fma((double)r03[1], pssm[j * 7 + 1], d);
+            d = fma((double)r03[2], pssm[j * 7 + 2], d);
+            d = fma((double)r03[3], pssm[j * 7 + 3], d);
+            d = fma((double)r45[0], pssm[j * 7 + 4], d);
+            d = fma((double)r45[1], pssm[j * 7 + 5], d);
+            d = fma((double)r6, pssm[j * 7 + 6], d);
             score += nan_to_num(d);
         }
         sq = cand_seq[i];
