@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpfmscan.so")
+LIB_PATH = os.environ.get("PFMSCAN_LIB") or os.path.join(HERE, "libpfmscan.so")   # override: A/B of two builds
 
 OK = 0
 E_BADARG, E_BADSHAPE, E_OOM, E_HIP, E_CAPACITY = -1, -2, -3, -4, -5
