@@ -196,3 +196,27 @@ def test_tsv_writer_matches_pandas_to_csv(golden):
     out = io.StringIO()
     table.write_frame(out, gdf.drop(columns="Match_ID"))
     assert out.getvalue() == g["tsv"]
+
+
+# ---- property-based host invariants -----------------------------------------------------
+def test_pack_locate_partition_properties():
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(0, 50), min_size=1, max_size=30), st.integers(1, 12), st.integers(1, 9))
+    def run(lengths, m, world):
+        codes = [np.full(L, i % 4, dtype=np.uint8) for i, L in enumerate(lengths)]
+        s = pack.pack(codes)
+        assert s.n_pos == sum(lengths) + len(lengths)
+        assert (s.codes[s.offsets + s.lengths] == pack.SEP).all()           # one separator after every record
+        mask = s.window_mask(m)
+        assert mask.sum() == s.n_windows(m) == sum(max(L - m + 1, 0) for L in lengths)
+        pos = np.flatnonzero(mask)
+        rec, start = s.locate(pos)
+        assert ((start >= 0) & (start + m <= s.lengths[rec])).all()
+        assert (s.offsets[rec] + start == pos).all()
+        parts = shard.partition(lengths, world)
+        assert parts[0][0] == 0 and parts[-1][1] == len(lengths)
+        assert all(a <= b for a, b in parts) and all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+
+    run()
