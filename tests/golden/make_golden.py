@@ -380,6 +380,32 @@ def main():
     run_avg("synth_w12_pc0_aligned", synth_path, synth_pssm0, "aligned", ninf, store_profile=True)
     run_avg("synth_w12_pc001_aligned", synth_path, synth_pssm1, "aligned", ninf, store_profile=True)
     run_avg("synth_w12_pc0_positional", synth_path, synth_pssm0, "positional", ninf, store_profile=True)
+    # a longer profile, width 18, background with a ZERO entry -> +inf log-odds next to the -inf ones:
+    # +DBL_MAX / -DBL_MAX row-dots, inf - inf -> NaN -> 0 inside one window (rnascan.py:306)
+    prof2 = rng.dirichlet(np.full(7, 0.25), size=150)
+    prof2[prof2 < 0.03] = 0.0
+    prof2 /= prof2.sum(axis=1, keepdims=True)
+    synth2_path = os.path.join(tmp, "structure.synth2.txt")
+    with open(synth2_path, "w") as f:
+        f.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+        for i, row in enumerate(prof2):
+            f.write(str(i) + "\t" + "\t".join(str(float(x)) for x in row) + "\n")
+    counts18 = {l: list(rng.dirichlet(np.full(7, 0.5), size=18)[:, k]) for k, l in enumerate("EHTBLRM")}
+    zm = rng.random((18, 7)) < 0.12
+    for k, l in enumerate("EHTBLRM"):
+        for i in range(18):
+            if zm[i, k]:
+                counts18[l][i] = 0.0
+    for i in range(18):                       # letter E: background 0; counts 0 except two rows ->
+        if i not in (3, 11):                  # NaN cells (0/0) almost everywhere, +inf in rows 3 and 11
+            counts18["E"][i] = 0.0
+    bg_zero = {"E": 0.0, "H": 0.2, "T": 0.1, "B": 0.1, "L": 0.3, "R": 0.2, "M": 0.1}
+    pssm18 = oracle.log_odds(oracle.normalize(counts18, 0.0), bg_zero)
+    run_avg("synth_w18_pc0_bgzero_aligned", synth2_path, pssm18, "aligned", ninf, store_profile=True)
+    run_avg("synth_w18_pc0_bgzero_positional_thr", synth2_path, pssm18, "positional", -1e300, store_profile=True)
+    counts8 = {l: list(rng.dirichlet(np.full(7, 0.5), size=8)[:, k]) for k, l in enumerate("EHTBLRM")}
+    pssm8 = oracle.log_odds(oracle.normalize(counts8, 0.01), None)
+    run_avg("synth_w8_pc001_positional", synth2_path, pssm8, "positional", -5.0, store_profile=True)
     G["scan_averaged_structure"] = avg_cases
 
     # ---- scan_main directory branch + combine + _add_match_id -------------------
