@@ -34,7 +34,7 @@ def build_lib(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-fno-fast-math", "-Wall", "-Wno-pass-failed",
+           "-fno-fast-math", "-Wall",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

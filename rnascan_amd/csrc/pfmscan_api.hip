@@ -42,6 +42,8 @@ struct pfmscan_ctx {
 struct pfmscan_motif {
     pfmscan_ctx *ctx = nullptr;
     double *d_letters = nullptr;   // [m][8]
+    float *d_pairs = nullptr;      // [(m+1)/2][16] two-letter fp32 sums (4-letter alphabets only), see k_letters_pre
+    double pair_eps = 0.0;
     double *d_struct = nullptr;    // [m][7]
     int m = 0;
     int struct_finite = 0;
@@ -130,6 +132,7 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     if (const char *v = std::getenv("PFMSCAN_DMA")) ctx->tune.dma = std::atoi(v) != 0;
     if (const char *v = std::getenv("PFMSCAN_ABLATE")) ctx->tune.ablate = std::atoi(v);
     if (const char *v = std::getenv("PFMSCAN_TWO_PHASE")) ctx->tune.two_phase = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_PREFILTER")) ctx->tune.prefilter = std::atoi(v) != 0;
     *out = ctx;
     return PFMSCAN_OK;
 }
@@ -190,6 +193,33 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
         e = hipMalloc((void **)&mo->d_letters, sizeof(double) * m * 8);
         if (e == hipSuccess) e = hipMemcpy(mo->d_letters, letter_table, sizeof(double) * m * 8, hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && letter_table) {
+        // hits-mode prefilter table: only when the alphabet is the 4 codes 0..3 (columns 4..7 all NaN)
+        bool four = true;
+        for (int j = 0; j < m && four; ++j)
+            for (int c = 4; c < 8; ++c)
+                if (!std::isnan(letter_table[j * 8 + c])) four = false;
+        if (four) {
+            const int npair = (m + 1) / 2;
+            std::vector<float> pairs((size_t)npair * 16);
+            double bound = 0.0;
+            for (int t = 0; t < npair; ++t) {
+                double mx = 0.0;
+                for (int c0 = 0; c0 < 4; ++c0)
+                    for (int c1 = 0; c1 < 4; ++c1) {
+                        const double v = letter_table[(2 * t) * 8 + c0] + (2 * t + 1 < m ? letter_table[(2 * t + 1) * 8 + c1] : 0.0);
+                        pairs[(size_t)t * 16 + (c0 | c1 << 2)] = (float)v;
+                        if (std::isfinite(v)) mx = std::max(mx, std::fabs(v));
+                        if (std::isfinite(v) && std::fabs(v) > 1e30) four = false;   // fp32 would overflow to inf
+                    }
+                bound += mx;
+            }
+            // rounding of the entries + of the fp32 adds + of the exact score's float cast <= ~4e-6 * bound at 32 pairs
+            mo->pair_eps = bound * 0x1p-17 + 1e-30;
+            if (four) e = hipMalloc((void **)&mo->d_pairs, sizeof(float) * pairs.size());
+            if (four && e == hipSuccess) e = hipMemcpy(mo->d_pairs, pairs.data(), sizeof(float) * pairs.size(), hipMemcpyHostToDevice);
+        }
+    }
     if (e == hipSuccess && struct_pssm) {
         mo->struct_finite = 1;
         for (int i = 0; i < m * 7; ++i)
@@ -211,6 +241,7 @@ void pfmscan_motif_destroy(pfmscan_motif *mo)
     if (!mo) return;
     if (mo->ctx) (void)hipSetDevice(mo->ctx->device);
     if (mo->d_letters) (void)hipFree(mo->d_letters);
+    if (mo->d_pairs) (void)hipFree(mo->d_pairs);
     if (mo->d_struct) (void)hipFree(mo->d_struct);
     delete mo;
 }
@@ -237,6 +268,8 @@ static int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8
     a.profile_dtype = profile_dtype;
     a.n_pos = n_pos;
     a.letter_table = mo->d_letters;
+    a.pair_table = ctx->tune.prefilter ? mo->d_pairs : nullptr;
+    a.pair_eps = mo->pair_eps;
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;

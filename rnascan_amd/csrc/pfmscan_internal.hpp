@@ -13,6 +13,10 @@ struct ScanArgs {
     int profile_dtype;           // PFMSCAN_PROFILE_*
     int64_t n_pos;
     const double *letter_table;  // [m][8] device or null
+    const float *pair_table;     // [(m+1)/2][16] device or null: fp32 sums of two adjacent letters (4-letter alphabets),
+                                 // index c0 | c1 << 2 -- the hits-mode prefilter of k_letters_pre
+    int tiles_per_block;         // k_letters_pre: consecutive tiles one workgroup walks (set by the launcher)
+    double pair_eps;             // |fp32 pair-table score - exact score| <= pair_eps for every window
     const double *struct_pssm;   // [m][7] device or null
     int m;
     int struct_finite;           // every struct_pssm cell finite -> fast path legal
@@ -43,6 +47,7 @@ struct Tuning {
     int dma = 1;            // k_profile: stage the tile with LDS-DMA (global_load_lds, 2.34 ms on C3) instead of
                             // through registers (2.51 ms)
     int ablate = 0;         // see ScanArgs::ablate; results are WRONG when non-zero
+    int prefilter = 1;      // hits over 4-letter alphabets: fp32 two-letter prefilter, exact fp64 re-score of survivors
     int two_phase = 1;      // combined hits through the host/staged API: letters first, structure only at candidates
 };
 

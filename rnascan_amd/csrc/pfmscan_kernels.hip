@@ -76,6 +76,45 @@ __device__ __forceinline__ uint32_t load_codes4(const uint8_t *__restrict__ code
     return w;
 }
 
+// A tile's codes (TILE window starts + CODE_HALO bytes of look-ahead) as 16-byte vectors: global -> registers
+// (fetch_codes, issued early) -> LDS (park_codes).  Every thread then reads its own 8-byte-strided
+// dwords from LDS.  Loading them straight from global -- each thread its 6..7 overlapping dwords,
+// every cache line requested 7 times, a 64-bit bounds test per dword -- was HALF of k_letters' time.
+constexpr int CODE_HALO = 80;                         // >= W - 1 + PFMSCAN_MAX_M + 1, multiple of 16
+template <int TILE> struct CodeStage {
+    static constexpr int NVEC = (TILE + CODE_HALO) / 16;
+    static constexpr int PER = (NVEC + BLOCK - 1) / BLOCK;
+    u32x4 r[PER];
+    __device__ __forceinline__ void fetch(const uint8_t *__restrict__ codes, int64_t tile0, int64_t n_pos)
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * BLOCK;
+            const int64_t p = tile0 + 16 * (int64_t)i;
+            u32x4 v = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
+            if (i < NVEC) {
+                if (p + 16 <= n_pos) {
+                    v = *reinterpret_cast<const u32x4 *>(codes + p);
+                } else if (p < n_pos) {
+                    uint32_t t[4] = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
+                    for (int b = 0; b < 16; ++b)
+                        if (p + b < n_pos) t[b >> 2] = (t[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)codes[p + b] << (8 * (b & 3)));
+                    v = u32x4{t[0], t[1], t[2], t[3]};
+                }
+            }
+            r[k] = v;
+        }
+    }
+    __device__ __forceinline__ void park(uint8_t *cbuf) const
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * BLOCK;
+            if (i < NVEC) *reinterpret_cast<u32x4 *>(cbuf + 16 * i) = r[k];
+        }
+    }
+};
+
 // Append the hits of one workgroup: every thread brings N windows.  Counts are
 // scanned inside the wave (shuffles) and across the 4 waves (LDS), then ONE returning
 // atomic per workgroup reserves the slots -- and none at all when the workgroup has no
@@ -144,13 +183,16 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
     constexpr int LET_TILE = let_tile(NDW);
     constexpr int NW = NDW + (W - 4) / 4;              // code dwords per round: bytes 0 .. W + m - 2
     __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
+    __shared__ __align__(16) uint8_t cbuf[LET_TILE + CODE_HALO];
     const int m = a.m;
-    for (int i = threadIdx.x; i < m * 8; i += BLOCK) tbl[i] = a.letter_table[i];
-    __syncthreads();
-
     const int64_t n_pos = a.n_pos;
     const int64_t tile0 = (int64_t)blockIdx.x * LET_TILE;
-    const int ndneed = (W + m - 2) >> 2;               // highest dword index touched
+    CodeStage<LET_TILE> cs;
+    if (!(a.ablate & 2)) cs.fetch(a.codes, tile0, n_pos);
+    for (int i = threadIdx.x; i < m * 8; i += BLOCK) tbl[i] = a.letter_table[i];
+    if (!(a.ablate & 2)) cs.park(cbuf);
+    __syncthreads();
+
     OUT_T *__restrict__ out = reinterpret_cast<OUT_T *>(sizeof(OUT_T) == 4 ? (void *)a.out_seq : (void *)a.out_letters_f64);
 
     // Three phases per workgroup, so that no wave ever waits for its own stores: (1) every
@@ -165,8 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
         const int64_t p0 = tile0 + (int64_t)it * (BLOCK * W) + (int64_t)threadIdx.x * W;
 #pragma unroll
         for (int d = 0; d < NW; ++d) {
-            uint32_t x = 0x07070707u;
-            if (d <= ndneed && !(a.ablate & 2)) x = load_codes4(a.codes, p0 + 4 * d, n_pos);
+            const uint32_t x = *reinterpret_cast<const uint32_t *>(cbuf + (p0 - tile0) + 4 * d);   // inside the halo
             wall[it][d] = (x & 0x07070707u) << 3;      // byte = code * sizeof(double)
         }
     }
@@ -177,20 +218,18 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
         double acc[W];
 #pragma unroll
         for (int v = 0; v < W; ++v) acc[v] = 0.0;
+        // one guarded group per motif position: a guard, not a break (a constant trip count is what
+        // lets hipcc unroll this), and no wider groups (2 or 4 positions per guard keep more look-ups
+        // in flight but cost 2-3 waves of occupancy: 15-50 % slower at every width)
 #pragma unroll
-        for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
-            if (j0 >= m) break;
+        for (int j = 0; j < (NDW - 1) * 4; ++j) {
+            if (j < m) {
+                const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                if (j < m) {
-                    const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
-#pragma unroll
-                    for (int v = 0; v < W; ++v) {
-                        const int q = j + v;    // byte index relative to p0, compile-time
-                        const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
-                        acc[v] += *reinterpret_cast<const double *>(row + b);
-                    }
+                for (int v = 0; v < W; ++v) {
+                    const int q = j + v;    // byte index relative to p0, compile-time
+                    const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+                    acc[v] += *reinterpret_cast<const double *>(row + b);
                 }
             }
         }
@@ -280,6 +319,199 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_letters_pre -- hits mode over a 4-letter alphabet with an fp32 prefilter.
+// The exact score needs m dependent fp64 adds and m 8-byte LDS look-ups per window, and k_letters
+// is bound by exactly those (it reads 1 byte per window).  A hit only has to be EXACT once we
+// know it may be one: here every window first gets an approximate score from a table of
+// two-letter sums (fp32, [ceil(m/2)][16], 64-byte rows -> conflict-free ds_read_b32): half the
+// look-ups, half-width adds.  |approx - exact| <= pair_eps (bound computed on the host from the
+// table), so "approx > thr - pair_eps" loses no hit; the survivors are re-scored with the
+// sequential fp64 sum of _pwm.c:34-68 from the codes still in registers, and only that exact
+// float32 score is compared with the threshold and reported.  Foreign letters are invisible to
+// the prefilter (it looks at 2 bits per code) and rejected by the exact pass (NaN).
+//
+// A workgroup walks a.tiles_per_block consecutive tiles and parks its hits in an LDS queue that
+// it flushes with ONE returning atomic (and coalesced stores): at real thresholds every tile
+// holds a few hits, and one atomic per 4096 windows serialises on the counter word
+// (73k atomics = 0.45 ms on C2, more than the scoring itself).
+// ---------------------------------------------------------------------------
+constexpr int HITQ_CAP = 1024;
+
+template <int NDW>
+__global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
+{
+    constexpr int W = 8;
+    constexpr int ROUNDS = (let_iters(NDW) * 4) / W;
+    constexpr int N = ROUNDS * W;
+    constexpr int LET_TILE = let_tile(NDW);
+    constexpr int NW = NDW + 1;                        // code dwords per round: bytes 0 .. W + m - 1 (+1 for the pair)
+    __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
+    __shared__ __align__(16) float ptab[(PFMSCAN_MAX_M / 2) * 16];
+    __shared__ __align__(16) uint8_t cbuf[LET_TILE + CODE_HALO];
+    __shared__ int64_t q_pos[HITQ_CAP];
+    __shared__ float q_sc[HITQ_CAP];
+    __shared__ int q_n, s_run, hb_wave[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const int m = a.m;
+    const int npair = (m + 1) >> 1;
+    // rows m .. roundup4(m)-1 are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold
+    // (never -0.0), so the exact pass runs whole groups of 4 motif positions
+    for (int i = threadIdx.x; i < ((m + 3) & ~3) * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
+    for (int i = threadIdx.x; i < npair * 16; i += BLOCK) ptab[i] = a.pair_table[i];
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+
+    const int64_t n_pos = a.n_pos;
+    const double thr_lo = a.thr_seq - a.pair_eps;
+    const char *pbytes = (const char *)ptab;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int shard = blockIdx.x & (a.hit_shards - 1);
+    const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.capacity;
+    unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
+
+    auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
+        if ((int64_t)slot < a.capacity) {             // capacity is per shard
+            a.hit_pos[shard_off + slot] = pos;
+            if (a.hit_seq) a.hit_seq[shard_off + slot] = sc;
+            if (a.hit_struct) a.hit_struct[shard_off + slot] = (double)sc;
+        }
+    };
+    // all threads; q_n is stable on entry and 0 on exit
+    auto flush = [&]() {
+        const int n = q_n;
+        if (n == 0) return;
+        if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)n);
+        __syncthreads();
+        const unsigned long long base = s_base;
+        for (int i = threadIdx.x; i < n; i += BLOCK) store_hit(base + i, q_pos[i], q_sc[i]);
+        __syncthreads();
+        if (threadIdx.x == 0) q_n = 0;
+        __syncthreads();
+    };
+
+    // the next tile's codes are fetched into registers while this one is scored; they are parked
+    // in LDS once every thread is past the tile (the barriers of the hit scan see to that)
+    CodeStage<LET_TILE> cs;
+    const int64_t first = (int64_t)blockIdx.x * a.tiles_per_block * LET_TILE;
+    if (first < n_pos) cs.fetch(a.codes, first, n_pos);
+    for (int tb = 0; tb < a.tiles_per_block; ++tb) {
+        const int64_t tile0 = first + (int64_t)tb * LET_TILE;
+        if (tile0 >= n_pos) break;
+        cs.park(cbuf);
+        __syncthreads();
+        if (tb + 1 < a.tiles_per_block && tile0 + LET_TILE < n_pos) cs.fetch(a.codes, tile0 + LET_TILE, n_pos);
+
+        uint32_t mask = 0;
+        float exact[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) exact[i] = 0.f;
+
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int64_t p0 = tile0 + (int64_t)it * (BLOCK * W) + (int64_t)threadIdx.x * W;
+            uint32_t w[NW + 1];
+#pragma unroll
+            for (int d = 0; d < NW + 1; ++d) {
+                w[d] = *reinterpret_cast<const uint32_t *>(cbuf + (p0 - tile0) + 4 * d);   // inside the halo
+            }
+            // z[d] byte k = 4 * (c[4d+k] | c[4d+k+1] << 2): byte offset in a pair-table row of the pair at byte 4d+k
+            uint32_t z[NW];
+#pragma unroll
+            for (int d = 0; d < NW; ++d) {
+                const uint32_t x0 = (w[d] & 0x03030303u) << 2, x1 = (w[d + 1] & 0x03030303u) << 2;
+                z[d] = x0 | __builtin_amdgcn_alignbit(x1, x0, 6);
+            }
+            float acc[W];
+#pragma unroll
+            for (int v = 0; v < W; ++v) acc[v] = 0.f;
+#pragma unroll
+            for (int t = 0; t < (NDW - 1) * 2; ++t) {   // pairs: motif positions 2t, 2t+1
+                if (t < npair)
+#pragma unroll
+                for (int v = 0; v < W; ++v) {
+                    const int q = v + 2 * t;            // byte index of the pair's first letter, compile-time
+                    const uint32_t off = (z[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+                    acc[v] += *(const float *)(pbytes + off + t * 64);
+                }
+            }
+            // Survivors: k_letters' exact score.  A wave enters a window's branch only when one of
+            // its lanes survived there, so the cost stays bounded by k_letters' at any threshold.
+#pragma unroll
+            for (int v = 0; v < W; ++v) {
+                if ((double)acc[v] > thr_lo) {               // windows past the end hold SEP codes: NaN below
+                    double sc = 0.0;
+#pragma unroll
+                    for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
+                        if (j0 < m)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = v + j0 + u;
+                            const uint32_t c = (w[q >> 2] >> ((q & 3) * 8)) & 7u;
+                            sc += tbl[(j0 + u) * 8 + c];
+                        }
+                    }
+                    const float f = (float)sc;
+                    if ((double)f > a.thr_seq) {
+                        mask |= 1u << (W * it + v);
+                        exact[W * it + v] = f;
+                    }
+                }
+            }
+        }
+
+        // workgroup scan of the hit counts (position order inside the tile)
+        const int cnt = __popc(mask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) hb_wave[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < BLOCK / 64; ++k) {
+                const int t = hb_wave[k];
+                hb_wave[k] = run;
+                run += t;
+            }
+            s_run = run;
+        }
+        __syncthreads();
+        const int run = s_run;
+        if (run == 0) continue;                         // uniform; s_run / hb_wave / cbuf are next written behind a barrier
+        if (q_n + run > HITQ_CAP) flush();
+        const int64_t pbase = tile0 + (int64_t)threadIdx.x * W;
+        const int mine = hb_wave[wave] + incl - cnt;
+        if (run > HITQ_CAP) {                           // a tile denser than the queue goes straight out
+            if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)run);
+            __syncthreads();
+            unsigned long long slot = s_base + (unsigned long long)mine;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (mask & (1u << i)) store_hit(slot++, pbase + (int64_t)(i / W) * (BLOCK * W) + (i % W), exact[i]);
+            __syncthreads();
+        } else {
+            const int qn = q_n;
+            int slot = qn + mine;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (mask & (1u << i)) {
+                    q_pos[slot] = pbase + (int64_t)(i / W) * (BLOCK * W) + (i % W);
+                    q_sc[slot] = exact[i];
+                    ++slot;
+                }
+            __syncthreads();
+            if (threadIdx.x == 0) q_n = qn + run;
+            __syncthreads();
+        }
+    }
+    flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -729,7 +961,15 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
     // 8 windows per thread (hits: 0.39 vs 0.49 ms on C2 w=12; scores, with the LDS transpose that keeps
     // the stores 1 KiB contiguous: 0.39 vs 0.42 ms on C2 w=8; without the transpose 0.56 ms)
-    if (a.hits)
+    if (a.hits && a.pair_table) {
+        // >= 2048 workgroups when the stream allows, at most 8 tiles behind one atomic
+        ScanArgs b = a;
+        const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
+        b.tiles_per_block = (int)std::min<int64_t>(8, std::max<int64_t>(1, ntiles / 2048));
+        const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
+        hipLaunchKernelGGL((k_letters_pre<NDW>), dim3(g), dim3(BLOCK), 0, stream, b);
+    }
+    else if (a.hits)
         hipLaunchKernelGGL((k_letters<NDW, float, true, 8>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else if (a.out_letters_f64)
         hipLaunchKernelGGL((k_letters<NDW, double, false, 4>), dim3(grid), dim3(BLOCK), 0, stream, a);
