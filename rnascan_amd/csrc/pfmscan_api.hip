@@ -379,9 +379,10 @@ static int hits_core(pfmscan_ctx *ctx, const pfmscan_motif *mo, const ScanArgs &
     ScanArgs fused = base;
     fill_sink(fused, mo, sink, thr_seq, thr_struct);
     if (!two) return do_launch(ctx, fused, st);
-    // phase 1: letters only (1 B per position) -> candidates.  Measured on C3 (w = 12): letters pass 0.5 ms,
-    // verify ~0.2 ms per 1 % of candidates, fused pass 2.1 ms -> two passes pay while <= ~1/32 of the
-    // windows pass the letter threshold.  A pilot over a prefix of the stream estimates that rate first.
+    // phase 1: letters only (1 B per position) -> candidates.  Measured on C3 (w = 12): letters pass 0.23 ms,
+    // verify ~0.1 ms per 1 M candidates (0.3 % of the windows), fused pass 2.1 ms -> two passes pay while
+    // <= ~1/16 of the windows pass the letter threshold; the candidate buffers are sized for 1/32.
+    // A pilot over a prefix of the stream estimates that rate first.
     int rc;
     const int64_t cand_cap = std::max<int64_t>(n_pos / 32, 1024);
     const int64_t cand_shard_cap = std::min<int64_t>(cand_cap, cand_cap / HIT_SHARDS * 2 + 4096);

@@ -16,6 +16,7 @@ struct ScanArgs {
     const float *pair_table;     // [(m+1)/2][16] device or null: fp32 sums of two adjacent letters (4-letter alphabets),
                                  // index c0 | c1 << 2 -- the hits-mode prefilter of k_letters_pre
     int tiles_per_block;         // k_letters_pre: consecutive tiles one workgroup walks (set by the launcher)
+    float thr_pre;               // k_letters_pre: largest float <= thr_seq - pair_eps (set by the launcher)
     double pair_eps;             // |fp32 pair-table score - exact score| <= pair_eps for every window
     const double *struct_pssm;   // [m][7] device or null
     int m;

@@ -333,44 +333,57 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 // float32 score is compared with the threshold and reported.  Foreign letters are invisible to
 // the prefilter (it looks at 2 bits per code) and rejected by the exact pass (NaN).
 //
-// A workgroup walks a.tiles_per_block consecutive tiles and parks its hits in an LDS queue that
-// it flushes with ONE returning atomic (and coalesced stores): at real thresholds every tile
-// holds a few hits, and one atomic per 4096 windows serialises on the counter word
-// (73k atomics = 0.45 ms on C2, more than the scoring itself).
+// Hits are rare and found in divergent code, so they are not scanned into place: a hit lane takes
+// a slot of its wave's LDS queue with an LDS atomic.  A workgroup walks a.tiles_per_block tiles
+// (codes double-buffered in LDS, ONE barrier per tile) and at a tile boundary flushes the four
+// queues with ONE returning global atomic once one is half full, and at the end -- one atomic per
+// 4096 windows serialised on the counter word (73k atomics = 0.45 ms on C2, more than the
+// scoring).  A wave whose queue cannot take the survivors of the next 64 windows flushes alone
+// (dense thresholds only).  Hits land in no particular order; the host sorts.
 // ---------------------------------------------------------------------------
-constexpr int HITQ_CAP = 1024;
+constexpr int WQ_CAP = 256;                           // hits a wave can park
 
 template <int NDW>
 __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
 {
     constexpr int W = 8;
     constexpr int ROUNDS = (let_iters(NDW) * 4) / W;
-    constexpr int N = ROUNDS * W;
     constexpr int LET_TILE = let_tile(NDW);
     constexpr int NW = NDW + 1;                        // code dwords per round: bytes 0 .. W + m - 1 (+1 for the pair)
+    constexpr int NWAVE = BLOCK / 64;
     __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
     __shared__ __align__(16) float ptab[(PFMSCAN_MAX_M / 2) * 16];
-    __shared__ __align__(16) uint8_t cbuf[LET_TILE + CODE_HALO];
-    __shared__ int64_t q_pos[HITQ_CAP];
-    __shared__ float q_sc[HITQ_CAP];
-    __shared__ int q_n, s_run, hb_wave[BLOCK / 64];
+    __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
+    __shared__ int64_t q_pos[NWAVE][WQ_CAP];
+    __shared__ float q_sc[NWAVE][WQ_CAP];
+    __shared__ int q_n[NWAVE], snap[2][NWAVE];
     __shared__ unsigned long long s_base;
     const int m = a.m;
     const int npair = (m + 1) >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_pos = a.n_pos;
+    const int ntile = a.tiles_per_block;
+    const int64_t first = (int64_t)blockIdx.x * ntile * LET_TILE;
+    if (first >= n_pos) return;                        // whole workgroup
+
+    CodeStage<LET_TILE> cs;
+    cs.fetch(a.codes, first, n_pos);
     // rows m .. roundup4(m)-1 are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold
     // (never -0.0), so the exact pass runs whole groups of 4 motif positions
     for (int i = threadIdx.x; i < ((m + 3) & ~3) * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
     for (int i = threadIdx.x; i < npair * 16; i += BLOCK) ptab[i] = a.pair_table[i];
-    if (threadIdx.x == 0) q_n = 0;
+    if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
+    cs.park(cbuf[0]);
+    if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
     __syncthreads();
 
-    const int64_t n_pos = a.n_pos;
-    const double thr_lo = a.thr_seq - a.pair_eps;
+    const float thr_pre = a.thr_pre;                   // largest float <= thr_seq - pair_eps
     const char *pbytes = (const char *)ptab;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int shard = blockIdx.x & (a.hit_shards - 1);
     const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.capacity;
     unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
+    int64_t *my_pos = q_pos[wave];
+    float *my_sc = q_sc[wave];
 
     auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
         if ((int64_t)slot < a.capacity) {             // capacity is per shard
@@ -379,44 +392,40 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
             if (a.hit_struct) a.hit_struct[shard_off + slot] = (double)sc;
         }
     };
-    // all threads; q_n is stable on entry and 0 on exit
-    auto flush = [&]() {
-        const int n = q_n;
+    // this wave's queue -> global at base; all 64 lanes (LDS operations of one wave execute in order)
+    auto drain = [&](unsigned long long base, int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < n; i += 64) store_hit(base + i, my_pos[i], my_sc[i]);
+        if (lane == 0) q_n[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto wave_flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = __builtin_amdgcn_readfirstlane(q_n[wave]);
         if (n == 0) return;
-        if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)n);
-        __syncthreads();
-        const unsigned long long base = s_base;
-        for (int i = threadIdx.x; i < n; i += BLOCK) store_hit(base + i, q_pos[i], q_sc[i]);
-        __syncthreads();
-        if (threadIdx.x == 0) q_n = 0;
-        __syncthreads();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned long long)n);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        drain(((unsigned long long)hi << 32) | lo, n);
     };
 
-    // the next tile's codes are fetched into registers while this one is scored; they are parked
-    // in LDS once every thread is past the tile (the barriers of the hit scan see to that)
-    CodeStage<LET_TILE> cs;
-    const int64_t first = (int64_t)blockIdx.x * a.tiles_per_block * LET_TILE;
-    if (first < n_pos) cs.fetch(a.codes, first, n_pos);
-    for (int tb = 0; tb < a.tiles_per_block; ++tb) {
+    int qn_ub = 0;                                     // wave-uniform upper bound of q_n[wave]
+    for (int tb = 0; tb < ntile; ++tb) {
         const int64_t tile0 = first + (int64_t)tb * LET_TILE;
-        if (tile0 >= n_pos) break;
-        cs.park(cbuf);
-        __syncthreads();
-        if (tb + 1 < a.tiles_per_block && tile0 + LET_TILE < n_pos) cs.fetch(a.codes, tile0 + LET_TILE, n_pos);
-
-        uint32_t mask = 0;
-        float exact[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) exact[i] = 0.f;
+        if (tile0 >= n_pos) break;                     // uniform; the previous tile flushed (it was the last)
+        const uint8_t *cb = cbuf[tb & 1];
 
 #pragma unroll
         for (int it = 0; it < ROUNDS; ++it) {
-            const int64_t p0 = tile0 + (int64_t)it * (BLOCK * W) + (int64_t)threadIdx.x * W;
+            const int off0 = it * (BLOCK * W) + threadIdx.x * W;
             uint32_t w[NW + 1];
 #pragma unroll
-            for (int d = 0; d < NW + 1; ++d) {
-                w[d] = *reinterpret_cast<const uint32_t *>(cbuf + (p0 - tile0) + 4 * d);   // inside the halo
-            }
+            for (int d = 0; d < NW + 1; ++d) w[d] = *reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d);   // inside the halo
             // z[d] byte k = 4 * (c[4d+k] | c[4d+k+1] << 2): byte offset in a pair-table row of the pair at byte 4d+k
             uint32_t z[NW];
 #pragma unroll
@@ -439,79 +448,65 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
             }
             // Survivors: k_letters' exact score.  A wave enters a window's branch only when one of
             // its lanes survived there, so the cost stays bounded by k_letters' at any threshold.
+            // (Windows past the end hold SEP codes: NaN below.)
 #pragma unroll
             for (int v = 0; v < W; ++v) {
-                if ((double)acc[v] > thr_lo) {               // windows past the end hold SEP codes: NaN below
-                    double sc = 0.0;
-#pragma unroll
-                    for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
-                        if (j0 < m)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int q = v + j0 + u;
-                            const uint32_t c = (w[q >> 2] >> ((q & 3) * 8)) & 7u;
-                            sc += tbl[(j0 + u) * 8 + c];
-                        }
+                const bool sv = acc[v] > thr_pre;
+                const unsigned long long sb = __ballot(sv);
+                if (sb) {                               // wave-uniform
+                    const int ns = __popcll(sb);
+                    if (qn_ub + ns > WQ_CAP) {
+                        wave_flush();
+                        qn_ub = 0;
                     }
-                    const float f = (float)sc;
-                    if ((double)f > a.thr_seq) {
-                        mask |= 1u << (W * it + v);
-                        exact[W * it + v] = f;
+                    qn_ub += ns;
+                    if (sv) {
+                        double sc = 0.0;
+#pragma unroll
+                        for (int j0 = 0; j0 < (NDW - 1) * 4; j0 += 4) {
+                            if (j0 < m)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int q = v + j0 + u;
+                                const uint32_t c = (w[q >> 2] >> ((q & 3) * 8)) & 7u;
+                                sc += tbl[(j0 + u) * 8 + c];
+                            }
+                        }
+                        const float f = (float)sc;
+                        if ((double)f > a.thr_seq) {
+                            const int slot = atomicAdd(&q_n[wave], 1);     // LDS
+                            my_pos[slot] = tile0 + off0 + v;
+                            my_sc[slot] = f;
+                        }
                     }
                 }
             }
         }
 
-        // workgroup scan of the hit counts (position order inside the tile)
-        const int cnt = __popc(mask);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(incl, d);
-            if (lane >= d) incl += y;
-        }
-        if (lane == 63) hb_wave[wave] = incl;
+        // tile boundary: publish the next tile's codes and this wave's queue length, ONE barrier
+        const bool more = tb + 1 < ntile && tile0 + LET_TILE < n_pos;
+        if (more) cs.park(cbuf[(tb + 1) & 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) snap[tb & 1][wave] = q_n[wave];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
+        if (tb + 2 < ntile && tile0 + 2 * (int64_t)LET_TILE < n_pos) cs.fetch(a.codes, tile0 + 2 * (int64_t)LET_TILE, n_pos);
+        int nq[NWAVE], total = 0, most = 0, before = 0;
 #pragma unroll
-            for (int k = 0; k < BLOCK / 64; ++k) {
-                const int t = hb_wave[k];
-                hb_wave[k] = run;
-                run += t;
-            }
-            s_run = run;
+        for (int k = 0; k < NWAVE; ++k) {
+            nq[k] = snap[tb & 1][k];
+            if (k < wave) before += nq[k];
+            total += nq[k];
+            most = most > nq[k] ? most : nq[k];
         }
-        __syncthreads();
-        const int run = s_run;
-        if (run == 0) continue;                         // uniform; s_run / hb_wave / cbuf are next written behind a barrier
-        if (q_n + run > HITQ_CAP) flush();
-        const int64_t pbase = tile0 + (int64_t)threadIdx.x * W;
-        const int mine = hb_wave[wave] + incl - cnt;
-        if (run > HITQ_CAP) {                           // a tile denser than the queue goes straight out
-            if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)run);
+        qn_ub = nq[wave];
+        if (most >= WQ_CAP / 2 || (!more && total > 0)) {          // uniform: every thread read the same snapshot
+            if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)total);
             __syncthreads();
-            unsigned long long slot = s_base + (unsigned long long)mine;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-                if (mask & (1u << i)) store_hit(slot++, pbase + (int64_t)(i / W) * (BLOCK * W) + (i % W), exact[i]);
-            __syncthreads();
-        } else {
-            const int qn = q_n;
-            int slot = qn + mine;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-                if (mask & (1u << i)) {
-                    q_pos[slot] = pbase + (int64_t)(i / W) * (BLOCK * W) + (i % W);
-                    q_sc[slot] = exact[i];
-                    ++slot;
-                }
-            __syncthreads();
-            if (threadIdx.x == 0) q_n = qn + run;
-            __syncthreads();
+            drain(s_base + (unsigned long long)before, nq[wave]);
+            qn_ub = 0;
         }
     }
-    flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -877,52 +872,91 @@ __global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_prof
 // hits: one thread per candidate, m contiguous rows straight from global memory, the
 // exact per-row nan_to_num path.  Same filter, same scores, ~29x fewer bytes.
 // ---------------------------------------------------------------------------
+// The candidate counts live on the device, so the grid cannot be sized to them: a fixed grid of
+// workgroups strides over the 256-candidate chunks of all shards.  (A grid that covered every
+// shard's CAPACITY spent 70 us launching 74k workgroups that read a count and left.)
+constexpr int STRUCT_AT_MAX_SHARDS = 64;
+
 template <typename PROF_T>
 __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int64_t *__restrict__ cand_pos,
                                                      const float *__restrict__ cand_seq,
                                                      const unsigned long long *__restrict__ cand_count,
-                                                     const int64_t cand_shard_cap, const int blocks_per_shard)
+                                                     const int64_t cand_shard_cap, const int cand_shards)
 {
-    // workgroup -> (candidate shard, chunk of 256 candidates inside it)
-    const int shard = blockIdx.x / blocks_per_shard;
-    const int64_t first = (int64_t)(blockIdx.x % blocks_per_shard) * BLOCK;
-    unsigned long long n = cand_count[shard * HIT_COUNTER_STRIDE];
-    if ((int64_t)n > cand_shard_cap) n = (unsigned long long)cand_shard_cap;
-    if ((unsigned long long)first >= n) return;                 // workgroup-uniform
-    const int64_t i = first + threadIdx.x;
-    cand_pos += (int64_t)shard * cand_shard_cap;
-    cand_seq += (int64_t)shard * cand_shard_cap;
-    uint32_t mask = 0;
-    int64_t p = 0;
-    float sq = 0.f;
-    double score = 0.0;
-    if ((unsigned long long)i < n) {
-        p = cand_pos[i];
-        const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(a.profile) + p * 7;
-        const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)a.struct_pssm;
-        for (int j = 0; j < a.m; ++j) {
-            // one row = 7 contiguous values at element alignment: 16 + 8 + 4 bytes (or 2 x 16 + 16 + 8 for
-            // fp64) instead of 7 scalar loads -- the candidates are scattered, so this pass is bound by the
-            // number of vector-memory instructions, not by bytes
-            typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
-            typedef PROF_T v2_t __attribute__((ext_vector_type(2), aligned(sizeof(PROF_T))));
-            const PROF_T *r = prof + j * 7;
-            const v4_t r03 = *reinterpret_cast<const v4_t *>(r);
-            const v2_t r45 = *reinterpret_cast<const v2_t *>(r + 4);
-            const PROF_T r6 = r[6];
-            double d = (double)r03[0] * pssm[j * 7];
-            d = fma((double)r03[1], pssm[j * 7 + 1], d);
-            d = fma((double)r03[2], pssm[j * 7 + 2], d);
-            d = fma((double)r03[3], pssm[j * 7 + 3], d);
-            d = fma((double)r45[0], pssm[j * 7 + 4], d);
-            d = fma((double)r45[1], pssm[j * 7 + 5], d);
-            d = fma((double)r6, pssm[j * 7 + 6], d);
-            score += nan_to_num(d);
-        }
-        sq = cand_seq[i];
-        mask = score > a.thr_struct ? 1u : 0u;
+    __shared__ int chunk_end[STRUCT_AT_MAX_SHARDS];     // inclusive prefix of ceil(n_s / 256)
+    __shared__ int64_t shard_n[STRUCT_AT_MAX_SHARDS];
+    if ((int)threadIdx.x < cand_shards) {               // one count per lane: 32 dependent-latency loads in a row cost 60 us
+        int64_t n = (int64_t)cand_count[threadIdx.x * HIT_COUNTER_STRIDE];
+        if (n > cand_shard_cap) n = cand_shard_cap;
+        shard_n[threadIdx.x] = n;
+        chunk_end[threadIdx.x] = (int)((n + BLOCK - 1) / BLOCK);
     }
-    emit_hits_block<1>(mask, [&](int) { return p; }, [&](int) { return sq; }, [&](int) { return score; }, a);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int s = 0; s < cand_shards; ++s) {
+            run += chunk_end[s];
+            chunk_end[s] = run;
+        }
+    }
+    __syncthreads();
+    const int chunks = chunk_end[cand_shards - 1];
+    const int m = a.m;
+    const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)a.struct_pssm;
+    typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+
+    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {          // workgroup-uniform
+        int shard = 0;
+        while (chunk_end[shard] <= c) ++shard;
+        const int64_t i = (int64_t)(c - (shard ? chunk_end[shard - 1] : 0)) * BLOCK + threadIdx.x;
+        uint32_t mask = 0;
+        int64_t p = 0;
+        float sq = 0.f;
+        double score = 0.0;
+        if (i < shard_n[shard]) {
+            const int64_t at = (int64_t)shard * cand_shard_cap + i;
+            p = cand_pos[at];
+            sq = cand_seq[at];
+            const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(a.profile) + p * 7;
+            // The candidates are scattered, so this pass is bound by the number of vector-memory
+            // requests (every lane of a load touches its own cache line), not by bytes: 4 rows = 28
+            // contiguous values are fetched as 7 element-aligned 4-vectors (1.75 requests per row; 16 + 8 + 4
+            // bytes per row took 3).  The last group is moved back to end with the window, rows already
+            // added are skipped.  (A candidate's m rows lie inside the stream: its letters window had no
+            // separator in it.)
+            for (int j0 = 0; j0 < m; j0 += 4) {
+                PROF_T val[28];
+                int base = j0;
+                if (m >= 4) {
+                    base = j0 < m - 4 ? j0 : m - 4;
+                    const PROF_T *r = prof + base * 7;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const v4_t q = *reinterpret_cast<const v4_t *>(r + 4 * k);
+                        val[4 * k] = q[0];
+                        val[4 * k + 1] = q[1];
+                        val[4 * k + 2] = q[2];
+                        val[4 * k + 3] = q[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = base + u;
+                    if (j >= j0 && j < m) {
+                        double d = (double)val[u * 7] * pssm[j * 7];
+#pragma unroll
+                        for (int c = 1; c < 7; ++c) d = fma((double)val[u * 7 + c], pssm[j * 7 + c], d);
+                        score += nan_to_num(d);
+                    }
+                }
+            }
+            mask = score > a.thr_struct ? 1u : 0u;
+        }
+        emit_hits_block<1>(mask, [&](int) { return p; }, [&](int) { return sq; }, [&](int) { return score; }, a);
+    }
 }
 
 hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
@@ -930,15 +964,15 @@ hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const fl
                             hipStream_t stream)
 {
     if (cand_shard_cap <= 0 || cand_shards <= 0) return hipSuccess;
-    // the grid covers every shard's capacity; workgroups beyond a shard's device-side count exit at once
-    const int bps = (int)((cand_shard_cap + BLOCK - 1) / BLOCK);
-    const unsigned grid = (unsigned)(bps * cand_shards);
+    if (cand_shards > STRUCT_AT_MAX_SHARDS) return hipErrorInvalidValue;
+    const int64_t worst = (cand_shard_cap + BLOCK - 1) / BLOCK * cand_shards;
+    const unsigned grid = (unsigned)std::min<int64_t>(worst, 2048);          // 8 workgroups per CU
     if (a.profile_dtype == PFMSCAN_PROFILE_F64)
         hipLaunchKernelGGL(k_struct_at<double>, dim3(grid), dim3(BLOCK), 0, stream, a, cand_pos, cand_seq, cand_count,
-                           cand_shard_cap, bps);
+                           cand_shard_cap, cand_shards);
     else
         hipLaunchKernelGGL(k_struct_at<float>, dim3(grid), dim3(BLOCK), 0, stream, a, cand_pos, cand_seq, cand_count,
-                           cand_shard_cap, bps);
+                           cand_shard_cap, cand_shards);
     return hipGetLastError();
 }
 
@@ -962,10 +996,13 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
     // 8 windows per thread (hits: 0.39 vs 0.49 ms on C2 w=12; scores, with the LDS transpose that keeps
     // the stores 1 KiB contiguous: 0.39 vs 0.42 ms on C2 w=8; without the transpose 0.56 ms)
     if (a.hits && a.pair_table) {
-        // >= 2048 workgroups when the stream allows, at most 8 tiles behind one atomic
+        // >= 2048 workgroups when the stream allows, at most 32 tiles per workgroup
         ScanArgs b = a;
         const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
-        b.tiles_per_block = (int)std::min<int64_t>(8, std::max<int64_t>(1, ntiles / 2048));
+        b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+        const double lo = a.thr_seq - a.pair_eps;
+        b.thr_pre = (float)lo;
+        if ((double)b.thr_pre > lo) b.thr_pre = std::nextafterf(b.thr_pre, -INFINITY);
         const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
         hipLaunchKernelGGL((k_letters_pre<NDW>), dim3(g), dim3(BLOCK), 0, stream, b);
     }

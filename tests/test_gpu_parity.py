@@ -273,3 +273,117 @@ def test_c_program_through_the_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("OK")
+
+
+# ---------------------------------------------------------------------------
+# hits over a 4-letter alphabet: the fp32 two-letter prefilter (k_letters_pre) must lose no hit
+# and report only exact scores
+# ---------------------------------------------------------------------------
+def _seq_hits_want(oracle, s, T, thr):
+    want_seq = oracle.stream_seq(s.codes, T)
+    return want_seq, oracle.stream_hits(want_seq, None, thr, thr)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 7, 8, 15, 16, 17, 32, 33, 64])
+def test_prefilter_thresholds_on_existing_scores(ctx, oracle, m):
+    """thresholds set ON scores that occur (strict >: that score is out) and one float32 below (in)"""
+    rng = np.random.default_rng(1000 + m)
+    s = rand_stream(rng, 40, 0, 900, foreign=0.01)
+    T = rand_table(rng, m)
+    motif = ctx.motif(letter_table=T)
+    want_seq = oracle.stream_seq(s.codes, T)
+    finite = np.unique(want_seq[np.isfinite(want_seq)])
+    assert finite.size >= min(4 ** m, 10)
+    picks = np.unique(finite[np.linspace(finite.size * 0.6, finite.size - 1, 6).astype(int)])
+    for v in picks:
+        for thr in (float(v), float(np.nextafter(np.float32(v), np.float32(-np.inf)))):
+            pos, sq, _ = ctx.hits_host(motif, s.codes, thr_seq=thr)
+            want_pos = oracle.stream_hits(want_seq, None, thr, thr)
+            assert np.array_equal(pos, want_pos), (m, thr)
+            assert_f32_bits_equal(sq, want_seq[want_pos])
+    motif.close()
+
+
+def test_prefilter_foreign_letters_alias_to_high_scores(ctx, oracle):
+    """N / separator codes look like U (low two bits) to the prefilter: the exact pass must drop them"""
+    rng = np.random.default_rng(5)
+    m = 6
+    T = np.full((m, 8), np.nan)
+    T[:, :4] = -3.0
+    T[:, 3] = 2.0                                    # all-U scores 12
+    codes = []
+    for _ in range(50):
+        c = np.full(int(rng.integers(m, 60)), 3, dtype=np.uint8)
+        c[rng.integers(0, c.size, size=2)] = rng.choice([4, 5, 6, 7], size=2)
+        codes.append(c)
+    s = pack.pack(codes)
+    motif = ctx.motif(letter_table=T)
+    want_seq, want_pos = _seq_hits_want(oracle, s, T, 11.0)
+    pos, sq, _ = ctx.hits_host(motif, s.codes, thr_seq=11.0)
+    assert want_pos.size > 0 and np.array_equal(pos, want_pos)
+    assert_f32_bits_equal(sq, want_seq[want_pos])
+    motif.close()
+
+
+@pytest.mark.parametrize("kind", ["neg_inf", "pos_inf", "nan_cell", "huge", "beyond_fp32", "tiny"])
+def test_prefilter_special_table_values(ctx, oracle, kind):
+    rng = np.random.default_rng(77)
+    m = 9
+    T = rand_table(rng, m)
+    if kind == "neg_inf":
+        T[:, :4][rng.random((m, 4)) < 0.2] = -np.inf
+    elif kind == "pos_inf":
+        T[2, 1] = np.inf
+        T[5, 0] = -np.inf                            # +inf and -inf in one window: NaN, never a hit
+    elif kind == "nan_cell":
+        T[4, 2] = np.nan
+    elif kind == "huge":
+        T[:, :4] *= 1e28                             # inside fp32 range: prefilter stays on, with a wide margin
+    elif kind == "beyond_fp32":
+        T[:, :4] *= 1e36                             # would overflow fp32: the table is not built, exact kernel runs
+    elif kind == "tiny":
+        T[:, :4] *= 1e-42                            # fp32 subnormals
+    s = rand_stream(rng, 30, 0, 700, foreign=0.01)
+    motif = ctx.motif(letter_table=T)
+    want_seq = oracle.stream_seq(s.codes, T)
+    fin = want_seq[np.isfinite(want_seq)]
+    for thr in (-np.inf, float(np.median(fin)), float(np.quantile(fin, 0.99)), float(fin.max())):
+        pos, sq, _ = ctx.hits_host(motif, s.codes, thr_seq=thr)
+        want_pos = oracle.stream_hits(want_seq, None, thr, thr)
+        assert np.array_equal(pos, want_pos), (kind, thr)
+        assert_f32_bits_equal(sq, want_seq[want_pos])
+    motif.close()
+
+
+def test_prefilter_dense_hits_overflow_the_lds_queue(ctx, oracle):
+    """every window a hit: tiles denser than the 1024-entry queue go straight to global"""
+    rng = np.random.default_rng(9)
+    m = 5
+    T = rand_table(rng, m)
+    s = rand_stream(rng, 8, 30000, 40000, foreign=0.0)
+    motif = ctx.motif(letter_table=T)
+    for thr in (-1e9, -2.0):
+        want_seq, want_pos = _seq_hits_want(oracle, s, T, thr)
+        pos, sq, _ = ctx.hits_host(motif, s.codes, thr_seq=thr, capacity=s.codes.size)
+        assert np.array_equal(pos, want_pos)
+        assert_f32_bits_equal(sq, want_seq[want_pos])
+    motif.close()
+
+
+def test_prefilter_off_gives_the_same_hits(ctx, oracle, monkeypatch):
+    """PFMSCAN_PREFILTER=0 (the exact kernel only) and the default path agree"""
+    from rnascan_amd import _lib
+    rng = np.random.default_rng(12)
+    T = rand_table(rng, 8)
+    s = rand_stream(rng, 50, 100, 3000)
+    motif = ctx.motif(letter_table=T)
+    pos1, sq1, _ = ctx.hits_host(motif, s.codes, thr_seq=3.0)
+    monkeypatch.setenv("PFMSCAN_PREFILTER", "0")
+    plain = _lib.Context(0)
+    m2 = plain.motif(letter_table=T)
+    pos0, sq0, _ = plain.hits_host(m2, s.codes, thr_seq=3.0)
+    assert np.array_equal(pos0, pos1)
+    assert_f32_bits_equal(sq0, sq1)
+    m2.close()
+    plain.close()
+    motif.close()
