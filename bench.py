@@ -222,11 +222,12 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and args.mode == "scores" and not seq_only:
+        if os.path.exists(tfile) and args.mode == "scores":
             try:
-                tj = json.load(open(tfile))
-                if tj.get("records") == args.records and tj.get("length") == args.length and tj.get("width") == args.width:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                for tj in json.load(open(tfile)).get("entries", []):
+                    if (tj.get("workload") == args.workload and tj.get("records") == args.records
+                            and tj.get("length") == args.length and tj.get("width") == args.width):
+                        traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         result = {
@@ -260,7 +261,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_letters" if seq_only else "k_profile", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else "k_profile", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
