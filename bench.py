@@ -123,12 +123,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libpfmscan has no CPU fallback)")
+    # rehearsal on a one-GPU box: PFMSCAN_BENCH_REHEARSE=1 puts every rank on device 0 and rendezvous over gloo
+    # (RCCL refuses two ranks on one device); the product launch is one rank per GPU over RCCL
+    rehearse = os.environ.get("PFMSCAN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     ctx = _lib.Context(local_rank)
     table, spssm = make_pssms(args.width, args.variant)
@@ -206,7 +214,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps          # HIP events on the launch stream
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
