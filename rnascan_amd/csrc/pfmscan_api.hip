@@ -132,6 +132,7 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     if (const char *v = std::getenv("PFMSCAN_DMA")) ctx->tune.dma = std::atoi(v) != 0;
     if (const char *v = std::getenv("PFMSCAN_ABLATE")) ctx->tune.ablate = std::atoi(v);
     if (const char *v = std::getenv("PFMSCAN_TWO_PHASE")) ctx->tune.two_phase = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_TILES_PER_BLOCK")) ctx->tune.tiles_per_block = std::max(0, std::min(1024, std::atoi(v)));
     if (const char *v = std::getenv("PFMSCAN_PREFILTER")) ctx->tune.prefilter = std::atoi(v) != 0;
     *out = ctx;
     return PFMSCAN_OK;

@@ -49,6 +49,7 @@ struct Tuning {
                             // through registers (2.51 ms)
     int ablate = 0;         // see ScanArgs::ablate; results are WRONG when non-zero
     int prefilter = 1;      // hits over 4-letter alphabets: fp32 two-letter prefilter, exact fp64 re-score of survivors
+    int tiles_per_block = 0; // k_letters_pre: 0 = pick from the stream length; > 0 forces it (PFMSCAN_TILES_PER_BLOCK, tests)
     int two_phase = 1;      // combined hits through the host/staged API: letters first, structure only at candidates
 };
 

@@ -989,7 +989,7 @@ static hipError_t allow_full_lds(const void *kern)
 }
 
 template <int NDW>
-static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
+static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
     constexpr int LET_TILE = let_tile(NDW);
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
@@ -1000,6 +1000,7 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
         ScanArgs b = a;
         const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
         b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+        if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;      // tests: the multi-tile walk on small streams
         const double lo = a.thr_seq - a.pair_eps;
         b.thr_pre = (float)lo;
         if ((double)b.thr_pre > lo) b.thr_pre = std::nextafterf(b.thr_pre, -INFINITY);
@@ -1015,11 +1016,11 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-static hipError_t launch_letters(const ScanArgs &a, hipStream_t stream)
+static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
-    if (a.m <= 16) return launch_letters_ndw<5>(a, stream);
-    if (a.m <= 32) return launch_letters_ndw<9>(a, stream);
-    return launch_letters_ndw<17>(a, stream);
+    if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
+    if (a.m <= 32) return launch_letters_ndw<9>(a, t, stream);
+    return launch_letters_ndw<17>(a, t, stream);
 }
 
 template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, int DMA>
@@ -1065,7 +1066,7 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
 {
     *what = "launch";
     if (a.n_pos <= 0) return hipSuccess;
-    if (!a.struct_pssm) return launch_letters(a, stream);
+    if (!a.struct_pssm) return launch_letters(a, t, stream);
     if (a.out_letters_f64 || a.profile == nullptr) return hipErrorInvalidValue;
     const bool has_seq = a.letter_table != nullptr;
     if (a.profile_dtype == PFMSCAN_PROFILE_F64) {

@@ -64,6 +64,7 @@ def test_fullsize_properties(big, oracle):
     ht = torch.empty(cap, dtype=torch.float64, device=big["dev"])
     cnt = torch.zeros(1, dtype=torch.int64, device=big["dev"])
     motif = big["ctx"].motif(big["table"], big["spssm"])
+    torch.cuda.synchronize()                     # the zero fill runs on torch's stream, the scan on the ctx's own
     big["ctx"].hits_dev(motif, big["codes"].data_ptr(), big["profile"].data_ptr(), _lib.PROFILE_F32, big["n_pos"],
                         thr_s, thr_t, cap, hp.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
     big["ctx"].synchronize()
@@ -72,6 +73,43 @@ def test_fullsize_properties(big, oracle):
     order = torch.argsort(hp[:k])
     assert torch.equal(hp[:k][order], want)
     assert torch.equal(hs[:k][order], s1[want]) and torch.equal(ht[:k][order], t1[want])
+    # letters-only hits (k_letters_pre: fp32 prefilter, 32 tiles per workgroup, LDS hit queues) == thresholding
+    # the all-scores output, at a selective and at a dense threshold
+    lo_motif = big["ctx"].motif(letter_table=big["table"])
+    for thr in (6.0, -1.0):
+        want = torch.nonzero(s1.double() > thr).flatten()
+        cap = int(want.numel()) + 16
+        hp = torch.empty(cap, dtype=torch.int64, device=big["dev"])
+        hs = torch.empty(cap, dtype=torch.float32, device=big["dev"])
+        cnt = torch.zeros(1, dtype=torch.int64, device=big["dev"])
+        torch.cuda.synchronize()                 # the zero fill runs on torch's stream, the scan on the ctx's own
+        big["ctx"].hits_dev(lo_motif, big["codes"].data_ptr(), None, _lib.PROFILE_NONE, big["n_pos"],
+                            thr, -np.inf, cap, hp.data_ptr(), hs.data_ptr(), None, cnt.data_ptr())
+        big["ctx"].synchronize()
+        k = int(cnt.item())
+        assert k == int(want.numel()) and k > 100
+        order = torch.argsort(hp[:k])
+        assert torch.equal(hp[:k][order], want) and torch.equal(hs[:k][order], s1[want])
+        del hp, hs, want, order
+    lo_motif.close()
+    # the candidate-then-verify combined scan finds the same hits as thresholding both outputs
+    thr_s, thr_t = 5.0, -14.0
+    want = torch.nonzero((s1.double() > thr_s) & (t1 > thr_t)).flatten()
+    cap = int(want.numel()) + 16
+    hp = torch.empty(cap, dtype=torch.int64, device=big["dev"])
+    hs = torch.empty(cap, dtype=torch.float32, device=big["dev"])
+    ht = torch.empty(cap, dtype=torch.float64, device=big["dev"])
+    cnt = torch.zeros(1, dtype=torch.int64, device=big["dev"])
+    torch.cuda.synchronize()
+    big["ctx"].hits_adaptive_dev(motif, big["codes"].data_ptr(), big["profile"].data_ptr(), _lib.PROFILE_F32, big["n_pos"],
+                                 thr_s, thr_t, cap, hp.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
+    big["ctx"].synchronize()
+    k = int(cnt.item())
+    assert k == int(want.numel()) and k > 100
+    order = torch.argsort(hp[:k])
+    assert torch.equal(hp[:k][order], want) and torch.equal(hs[:k][order], s1[want])
+    assert float((ht[:k][order] - t1[want]).abs().max()) <= 1e-6      # per-row exact path vs fused chain
+    del hp, hs, ht, want, order
     # sampled records: stream position independence + oracle
     rng = np.random.default_rng(0)
     stride = L + 1

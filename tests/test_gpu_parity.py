@@ -387,3 +387,26 @@ def test_prefilter_off_gives_the_same_hits(ctx, oracle, monkeypatch):
     m2.close()
     plain.close()
     motif.close()
+
+
+@pytest.mark.parametrize("tpb", [2, 3, 7])
+def test_prefilter_multi_tile_walk(oracle, monkeypatch, tpb):
+    """a workgroup walking several tiles (double-buffered codes, queue flushes at tile boundaries and in
+    mid-tile at dense thresholds); forced on a small stream with PFMSCAN_TILES_PER_BLOCK"""
+    from rnascan_amd import _lib
+    monkeypatch.setenv("PFMSCAN_TILES_PER_BLOCK", str(tpb))
+    c = _lib.Context(0)
+    rng = np.random.default_rng(40 + tpb)
+    m = 10
+    T = rand_table(rng, m)
+    s = rand_stream(rng, 25, 500, 4000, foreign=0.003)          # ~ 14 tiles of 4096 positions, ragged tail
+    motif = c.motif(letter_table=T)
+    want_seq = oracle.stream_seq(s.codes, T)
+    fin = want_seq[np.isfinite(want_seq)]
+    for thr in (float(np.quantile(fin, 0.999)), float(np.quantile(fin, 0.9)), float(np.quantile(fin, 0.3)), -1e30):
+        want_pos = oracle.stream_hits(want_seq, None, thr, thr)
+        pos, sq, _ = c.hits_host(motif, s.codes, thr_seq=thr)      # (few workgroups -> skewed shards: let it grow)
+        assert np.array_equal(pos, want_pos), (tpb, thr)
+        assert_f32_bits_equal(sq, want_seq[want_pos])
+    motif.close()
+    c.close()
