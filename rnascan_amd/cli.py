@@ -129,9 +129,11 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None)):
         # packed profile store: the mapped file is already the stream the kernel reads
         fasta.eprint("Scanning averaged secondary structures ")
         ps = store.ProfileStore(source)
-        lo, hi = shard.partition(ps.lengths, world)[rank]
-        df = shard.gather_frames(scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing, lo, hi),
-                                 rank, world, dist)
+        ids = list(range(len(ps.ids)))                 # batches of record indices: the mapped file is sliced, not copied
+        df = shard.scan_sharded(ids, ps.lengths,
+                                lambda part: scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing,
+                                                                part[0] if part else 0, part[-1] + 1 if part else 0),
+                                rank, world, dist)
         fasta.eprint("Processed %d sequences" % len(ps.ids))
         return df
     if os.path.isdir(source):

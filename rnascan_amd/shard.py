@@ -56,12 +56,41 @@ def gather_frames(df, rank, world, dist=None):
     return pd.concat(frames, ignore_index=True)
 
 
-def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None):
-    """Run ``scan_fn(items[lo:hi])`` on this rank's contiguous range and gather
-    the tables on rank 0.  ``items`` is any sliceable list (records, profiles or
-    pairs of them), ``lengths`` their lengths."""
+def batches(lengths, lo, hi, max_positions):
+    """Cut records [lo, hi) into contiguous batches of at most ``max_positions`` stream
+    positions sum(L_r + 1) each (a record longer than that is a batch of its own)."""
+    out, start, acc = [], lo, 0
+    for r in range(lo, hi):
+        cost = int(lengths[r]) + 1
+        if r > start and acc + cost > max_positions:
+            out.append((start, r))
+            start, acc = r, 0
+        acc += cost
+    if hi > start or not out:
+        out.append((start, hi))
+    return out
+
+
+def batch_positions():
+    """Stream positions one launch may hold (RNASCAN_BATCH_POSITIONS, default 2**28 = 268 M:
+    7.5 GB of float32 or 15 GB of float64 profile rows on the device and in the packed host copy).
+    Larger inputs go through several launches; the tables are concatenated in record order."""
+    return max(1, int(os.environ.get("RNASCAN_BATCH_POSITIONS", str(1 << 28))))
+
+
+def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None, max_positions=None):
+    """Run ``scan_fn`` over this rank's contiguous range -- one call per batch of at
+    most ``max_positions`` stream positions -- and gather the tables on rank 0.
+    ``items`` is any sliceable list (records, profiles or pairs of them), ``lengths``
+    their lengths."""
     if rank is None or world is None:
         rank, world = env_rank_world()
     lo, hi = partition(lengths, world)[rank]
-    local = scan_fn(items[lo:hi])
+    parts = batches(lengths, lo, hi, max_positions or batch_positions())
+    frames = [scan_fn(items[a:b]) for a, b in parts]
+    if len(frames) == 1:
+        local = frames[0]
+    else:
+        full = [f for f in frames if f is not None and len(f)]
+        local = pd.concat(full, ignore_index=True) if full else frames[0]
     return gather_frames(local, rank, world, dist)

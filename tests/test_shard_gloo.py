@@ -99,3 +99,31 @@ def test_cli_under_two_gloo_ranks(tmp_path):
     assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
     assert open(tmp_path / "out.1.tsv").read() == ""
     assert single.getvalue().count("\n") > 10
+
+
+def test_batches_cover_the_range_in_order():
+    from rnascan_amd import shard
+    lengths = [5, 0, 9, 100, 3, 3, 3, 50]
+    for cap in (1, 4, 10, 12, 60, 10 ** 6):
+        parts = shard.batches(lengths, 1, 8, cap)
+        assert parts[0][0] == 1 and parts[-1][1] == 8
+        assert all(a < b for a, b in parts) and all(p[1] == q[0] for p, q in zip(parts, parts[1:]))
+        for a, b in parts:                                   # over the cap only when a single record is
+            assert sum(l + 1 for l in lengths[a:b]) <= cap or b - a == 1
+    assert shard.batches(lengths, 3, 3, 10) == [(3, 3)]
+
+
+def test_batched_scan_equals_one_launch(monkeypatch):
+    """RNASCAN_BATCH_POSITIONS bounds what one launch holds; the table does not change"""
+    from engines import OracleEngine
+    from rnascan_amd import fasta, scanner, shard
+    recs, P = _make_inputs()
+    eng = OracleEngine()
+    fn = lambda part: scanner.scan_records(eng, part, P, fasta.RNA, -2.0)   # noqa: E731
+    whole = shard.scan_sharded(recs, [len(r.seq) for r in recs], fn, rank=0, world=1)
+    calls = []
+    fn2 = lambda part: (calls.append(len(part)), fn(part))[1]               # noqa: E731
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "700")
+    cut = shard.scan_sharded(recs, [len(r.seq) for r in recs], fn2, rank=0, world=1)
+    assert len(calls) > 5 and sum(calls) == len(recs)
+    pd.testing.assert_frame_equal(whole.reset_index(drop=True), cut.reset_index(drop=True))
