@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpfmscan.so")
-SOURCES = ["pfmscan_kernels.hip", "pfmscan_api.hip"]
+SOURCES = ["pfmscan_kernels.hip", "pfmscan_api.hip", "pfmscan_sort.hip"]
 DEPS = SOURCES + ["pfmscan_internal.hpp", os.path.join("..", "..", "include", "pfmscan.h")]
 
 

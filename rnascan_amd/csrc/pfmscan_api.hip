@@ -31,6 +31,7 @@ struct pfmscan_ctx {
     char name[128] = {0};
     DevBuf codes, profile, out_seq, out_struct, hit_pos, hit_seq, hit_struct, count, table;
     DevBuf cand_pos, cand_seq, cand_count;      // candidates of the two-phase combined scan
+    DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, sort_seq, sort_struct;   // pfmscan_sort.hip
     // staged stream (pfmscan_stage)
     int64_t staged_n = -1;
     int staged_dtype = PFMSCAN_PROFILE_NONE;
@@ -148,7 +149,8 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
     }
     for (DevBuf *b : {&ctx->codes, &ctx->profile, &ctx->out_seq, &ctx->out_struct, &ctx->hit_pos,
                       &ctx->hit_seq, &ctx->hit_struct, &ctx->count, &ctx->table, &ctx->cand_pos, &ctx->cand_seq,
-                      &ctx->cand_count})
+                      &ctx->cand_count, &ctx->sort_keys_in, &ctx->sort_keys_out, &ctx->sort_vals_in, &ctx->sort_vals_out,
+                      &ctx->sort_temp, &ctx->sort_seq, &ctx->sort_struct})
         release(*b);
     delete ctx;
 }
@@ -590,27 +592,45 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, double thr_se
         return fail(ctx, PFMSCAN_E_CAPACITY, "hit buffer too small: " + std::to_string(total) + " hits, capacity " + std::to_string(capacity));
     }
     if (total == 0) return PFMSCAN_OK;
-    std::vector<int64_t> pos(total);
-    std::vector<float> sq(total);
-    std::vector<double> st(total);
-    size_t w = 0;
-    for (int s = 0; s < HIT_SHARDS; ++s) {
-        const size_t c = (size_t)counters[(size_t)s * HIT_COUNTER_STRIDE];
-        if (!c) continue;
-        const size_t off = (size_t)s * (size_t)shard_cap;
-        HIP_TRY(ctx, hipMemcpy(pos.data() + w, (const int64_t *)ctx->hit_pos.p + off, c * 8, hipMemcpyDeviceToHost));
-        if (mo->d_letters) HIP_TRY(ctx, hipMemcpy(sq.data() + w, (const float *)ctx->hit_seq.p + off, c * 4, hipMemcpyDeviceToHost));
-        if (mo->d_struct) HIP_TRY(ctx, hipMemcpy(st.data() + w, (const double *)ctx->hit_struct.p + off, c * 8, hipMemcpyDeviceToHost));
-        w += c;
+    // shards -> one run in position order, on the device (pfmscan_sort.hip); three contiguous copies come back
+    int key_bits = 1;
+    while (key_bits < 63 && ((int64_t)1 << key_bits) < n_pos) ++key_bits;
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, sort_temp_bytes((int64_t)total, key_bits, &temp_bytes));
+    if ((rc = ensure(ctx, ctx->sort_keys_in, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_keys_out, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals_in, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals_out, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_temp, std::max<size_t>(temp_bytes, 256)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_seq, total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_struct, total * 8))) return rc;
+    GatherArgs g;
+    g.hit_pos = (const int64_t *)ctx->hit_pos.p;
+    g.hit_seq = mo->d_letters ? (const float *)ctx->hit_seq.p : nullptr;
+    g.hit_struct = mo->d_struct ? (const double *)ctx->hit_struct.p : nullptr;
+    g.counts = (const unsigned long long *)ctx->count.p;
+    g.shards = HIT_SHARDS;
+    g.shard_cap = shard_cap;
+    g.total = (int64_t)total;
+    g.key_bits = key_bits;
+    g.keys_in = (int64_t *)ctx->sort_keys_in.p;
+    g.keys_out = (int64_t *)ctx->sort_keys_out.p;
+    g.vals_in = (int64_t *)ctx->sort_vals_in.p;
+    g.vals_out = (int64_t *)ctx->sort_vals_out.p;
+    g.temp = ctx->sort_temp.p;
+    g.temp_bytes = ctx->sort_temp.cap;
+    g.seq_out = (float *)ctx->sort_seq.p;
+    g.struct_out = (double *)ctx->sort_struct.p;
+    {
+        hipError_t e = launch_gather_sorted(g, ctx->stream);
+        if (e != hipSuccess) return fail_hip(ctx, e, "gather + sort of the hits");
     }
-    std::vector<int64_t> order(total);
-    std::iota(order.begin(), order.end(), (int64_t)0);
-    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return pos[x] < pos[y]; });
-    for (uint64_t i = 0; i < total; ++i) {
-        hit_pos[i] = pos[order[i]];
-        if (hit_seq) hit_seq[i] = mo->d_letters ? sq[order[i]] : NAN;
-        if (hit_struct) hit_struct[i] = mo->d_struct ? st[order[i]] : NAN;
-    }
+    HIP_TRY(ctx, hipMemcpyAsync(hit_pos, g.keys_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_seq && mo->d_letters) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_struct && mo->d_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hit_seq && !mo->d_letters) std::fill(hit_seq, hit_seq + total, NAN);
+    if (hit_struct && !mo->d_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
     return PFMSCAN_OK;
 }
 

@@ -64,4 +64,24 @@ hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const fl
                             const unsigned long long *cand_count, int cand_shards, int64_t cand_shard_cap,
                             hipStream_t stream);
 
+// Sharded hit buffers -> one run sorted by position (pfmscan_sort.hip): keys_out holds the positions,
+// seq_out / struct_out the scores in the same order.  All pointers are device memory.
+struct GatherArgs {
+    const int64_t *hit_pos;
+    const float *hit_seq;                 // may be null
+    const double *hit_struct;             // may be null
+    const unsigned long long *counts;     // shards counters, HIT_COUNTER_STRIDE words apart
+    int shards;
+    int64_t shard_cap;
+    int64_t total;                        // sum over shards of min(count, shard_cap)
+    int key_bits;                         // bits a stream position can have
+    int64_t *keys_in, *keys_out, *vals_in, *vals_out;   // [total] each
+    void *temp;
+    size_t temp_bytes;                    // >= sort_temp_bytes(total, key_bits)
+    float *seq_out;                       // [total]
+    double *struct_out;                   // [total]
+};
+hipError_t sort_temp_bytes(int64_t total, int key_bits, size_t *bytes);
+hipError_t launch_gather_sorted(const GatherArgs &g, hipStream_t stream);
+
 }  // namespace pfmscan
