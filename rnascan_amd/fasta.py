@@ -118,18 +118,19 @@ def load_background(bg_file, uniform, fasta_files, letters, verbose=True):
 
 def read_profile(struct_file):
     """An averaged-structure profile file (written by pfmutil.py:61-87): header
-    ``PO`` + letters, one row per position.  Returns (letters, float64 [L][n])."""
-    with open(struct_file) as fh:
-        header = fh.readline().rstrip("\r\n").split("\t")
-        letters = header[1:]
-        rows = []
-        for line in fh:
-            line = line.rstrip("\r\n")
-            if not line:
-                continue
-            parts = line.split("\t")
-            rows.append([float(x) for x in parts[1:]])
-    prof = np.array(rows, dtype=np.float64).reshape(-1, len(letters))
+    ``PO`` + letters, one row per position.  Returns (letters, float64 [L][n]).
+
+    Parsed the way rnascan.py:296-297 does it (``pd.read_table`` then ``del struct['PO']``),
+    so the float64 values are the ones the reference computes with, bit for bit (pandas'
+    default converter is not always the correctly rounded one ``float()`` is)."""
+    import pandas as pd
+    df = pd.read_table(struct_file)
+    if "PO" in df.columns:
+        del df["PO"]
+    else:
+        df = df.iloc[:, 1:]
+    letters = [str(c) for c in df.columns]
+    prof = np.ascontiguousarray(df.to_numpy(dtype=np.float64)).reshape(-1, len(letters))
     return letters, prof
 
 
