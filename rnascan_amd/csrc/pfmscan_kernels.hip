@@ -864,6 +864,54 @@ __global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_prof
 }
 
 // ---------------------------------------------------------------------------
+// Exact structure score of the window at stream position p, rows straight from global memory
+// (rnascan.py:302-307: score += nan_to_num(dot(profile[p+j], pssm[j]))).  Used where the windows are
+// scattered (verification of letter-side candidates), so the cost is the number of vector-memory REQUESTS
+// (every lane touches its own cache line), not bytes: 4 rows = 28 contiguous values are fetched as 7
+// element-aligned 4-vectors (1.75 requests per row; 16 + 8 + 4 bytes per row took 3).  The last group is
+// moved back to end with the window, rows already added are skipped.  The window's m rows must lie inside
+// the stream (true for every window whose letters have no separator).
+// ---------------------------------------------------------------------------
+template <typename PROF_T>
+__device__ __forceinline__ double struct_score_at(const void *profile, int64_t p, int m, const double *struct_pssm)
+{
+    typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+    const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(profile) + p * 7;
+    const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)struct_pssm;
+    double score = 0.0;
+    for (int j0 = 0; j0 < m; j0 += 4) {
+        PROF_T val[28];
+        int base = j0;
+        if (m >= 4) {
+            base = j0 < m - 4 ? j0 : m - 4;
+            const PROF_T *r = prof + base * 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const v4_t q = *reinterpret_cast<const v4_t *>(r + 4 * k);
+                val[4 * k] = q[0];
+                val[4 * k + 1] = q[1];
+                val[4 * k + 2] = q[2];
+                val[4 * k + 3] = q[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base + u;
+            if (j >= j0 && j < m) {
+                double d = (double)val[u * 7] * pssm[j * 7];
+#pragma unroll
+                for (int c = 1; c < 7; ++c) d = fma((double)val[u * 7 + c], pssm[j * 7 + c], d);
+                score += nan_to_num(d);
+            }
+        }
+    }
+    return score;
+}
+
+// ---------------------------------------------------------------------------
 // k_struct_at -- verify phase of the candidate-then-verify combined scan.
 // A combined hit needs seq > thr AND struct > thr (rnascan.py:422-433 joins two
 // independently thresholded tables), and at real thresholds the letter side passes a
@@ -902,8 +950,6 @@ __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int
     __syncthreads();
     const int chunks = chunk_end[cand_shards - 1];
     const int m = a.m;
-    const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)a.struct_pssm;
-    typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
 
     for (int c = blockIdx.x; c < chunks; c += gridDim.x) {          // workgroup-uniform
         int shard = 0;
@@ -917,42 +963,7 @@ __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int
             const int64_t at = (int64_t)shard * cand_shard_cap + i;
             p = cand_pos[at];
             sq = cand_seq[at];
-            const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(a.profile) + p * 7;
-            // The candidates are scattered, so this pass is bound by the number of vector-memory
-            // requests (every lane of a load touches its own cache line), not by bytes: 4 rows = 28
-            // contiguous values are fetched as 7 element-aligned 4-vectors (1.75 requests per row; 16 + 8 + 4
-            // bytes per row took 3).  The last group is moved back to end with the window, rows already
-            // added are skipped.  (A candidate's m rows lie inside the stream: its letters window had no
-            // separator in it.)
-            for (int j0 = 0; j0 < m; j0 += 4) {
-                PROF_T val[28];
-                int base = j0;
-                if (m >= 4) {
-                    base = j0 < m - 4 ? j0 : m - 4;
-                    const PROF_T *r = prof + base * 7;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        const v4_t q = *reinterpret_cast<const v4_t *>(r + 4 * k);
-                        val[4 * k] = q[0];
-                        val[4 * k + 1] = q[1];
-                        val[4 * k + 2] = q[2];
-                        val[4 * k + 3] = q[3];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = base + u;
-                    if (j >= j0 && j < m) {
-                        double d = (double)val[u * 7] * pssm[j * 7];
-#pragma unroll
-                        for (int c = 1; c < 7; ++c) d = fma((double)val[u * 7 + c], pssm[j * 7 + c], d);
-                        score += nan_to_num(d);
-                    }
-                }
-            }
+            score = struct_score_at<PROF_T>(a.profile, p, m, a.struct_pssm);
             mask = score > a.thr_struct ? 1u : 0u;
         }
         emit_hits_block<1>(mask, [&](int) { return p; }, [&](int) { return sq; }, [&](int) { return score; }, a);

@@ -14,14 +14,15 @@ def main():
     ctx = _lib.Context(0)
     t = time.perf_counter(); ctx.stage(codes, None); print("stage %.1f ms" % ((time.perf_counter() - t) * 1e3))
     motifs = [ctx.motif(bench.make_pssms(w, "finite", seed=1000 + k)[0], None) for k in range(n_motifs)]
-    for rep in range(2):
-        t = time.perf_counter()
-        tot = 0
-        for mo in motifs:
-            pos, sq, _ = ctx.hits_staged(mo, thr_seq=thr)
-            tot += pos.size
-        dt = time.perf_counter() - t
-        print("rep %d: %d motifs, %d hits, %.2f ms per motif" % (rep, n_motifs, tot, dt / n_motifs * 1e3))
+    for thr_k in (thr, 9.0, 30.0):
+        for rep in range(2):
+            t = time.perf_counter()
+            tot = 0
+            for mo in motifs:
+                pos, sq, _ = ctx.hits_staged(mo, thr_seq=thr_k)
+                tot += pos.size
+            dt = time.perf_counter() - t
+            print("thr %.0f rep %d: %d motifs, %d hits, %.2f ms per motif" % (thr_k, rep, n_motifs, tot, dt / n_motifs * 1e3))
     if hasattr(ctx, "hits_library_staged"):
         for rep in range(2):
             t = time.perf_counter()
