@@ -6,16 +6,21 @@
 //
 // Kernels (DESIGN.md section 5 has the measurements behind each choice):
 //
-//  k_letters   codes only (config 2, the letter-string structure scan, and the
-//              first pass of the combined hits scan).  A thread owns W = 4 (scores)
-//              or 8 (hits) consecutive windows per round; it loads its code bytes
-//              plus the (m-1)-byte halo as dwords straight from global, looks each
-//              letter up in an LDS copy of the [m][8] log-odds table (ds_read_b64;
-//              all lanes of an instruction hit the SAME table row -> at most 8
-//              distinct addresses on 16 distinct banks, no conflict) and writes 4
-//              float32 scores as ONE 16-byte store, so a wave-instruction writes
-//              1 KiB contiguous.  All loads first, all stores last (vmcnt is one
-//              in-order queue for loads and stores).
+//  k_letters   codes only (config 2 and the letter-string structure scan).  A workgroup
+//              parks its tile's codes in LDS once (16-byte vector loads); a thread owns
+//              8 (float32 / hits) or 4 (fp64 output) consecutive windows per round, looks
+//              each letter up in an LDS copy of the [m][8] log-odds table (ds_read_b64;
+//              all lanes of an instruction hit the SAME table row -> at most 8 distinct
+//              addresses on 16 distinct banks, no conflict) and adds sequentially in fp64.
+//              float32 scores leave through a wave-private LDS transpose as 16-byte
+//              stores, 1 KiB contiguous per wave-instruction.  All code reads first, all
+//              stores last (vmcnt is one in-order queue for loads and stores).
+//
+//  k_letters_pre  hits over a 4-letter alphabet (the CLI's default path at -m 6, and the
+//              first pass of the combined hits scan): an fp32 score from a table of
+//              two-letter sums decides which windows can reach the threshold; only those
+//              get the exact fp64 score.  Hits go to per-wave LDS queues, one returning
+//              global atomic per workgroup flush.
 //
 //  k_profile   codes + averaged-structure profile (config 3, the headline).
 //              A workgroup stages one tile of T = 256*V positions (+ m halo rows)
@@ -33,7 +38,8 @@
 //              16-byte nontemporal stores.
 //
 //  k_struct_at structure score at a list of candidate windows (second pass of the
-//              candidate-then-verify combined hits scan).
+//              candidate-then-verify combined hits scan): a fixed grid strides over the
+//              sharded candidate lists, 4 profile rows per 7 vector loads.
 //
 // Reference semantics restated here (upstream paths, v0.10.2):
 //   _pwm.c:34-68       score = 0.0 (double); score += M[j][col]; (float)score;
