@@ -410,3 +410,29 @@ def test_prefilter_multi_tile_walk(oracle, monkeypatch, tpb):
         assert_f32_bits_equal(sq, want_seq[want_pos])
     motif.close()
     c.close()
+
+
+def test_host_hits_come_back_sorted_at_millions_of_hits(ctx, oracle):
+    """the device-side pack + radix sort + gather of the sharded hit buffers (pfmscan_sort.hip) on a stream
+    long enough for several sort passes and many workgroups per shard; seq-only and seq + struct"""
+    rng = np.random.default_rng(2024)
+    m = 6
+    T, P = rand_table(rng, m), rand_struct_pssm(rng, m) * 0.2 + 0.5
+    s = rand_stream(rng, 1500, 2000, 3500, foreign=0.001)
+    want_seq, want_st = oracle.stream_seq(s.codes, T), oracle.stream_struct(s.profile, P)
+    only = ctx.motif(letter_table=T)
+    pos, sq, _ = ctx.hits_host(only, s.codes, thr_seq=-0.5)
+    want = oracle.stream_hits(want_seq, None, -0.5, -0.5)
+    assert want.size > 1_000_000
+    assert np.array_equal(pos, want)
+    assert_f32_bits_equal(sq, want_seq[want])
+    only.close()
+    both = ctx.motif(T, P)
+    for thr in (-1.0, 1.5):                                  # fused pass (not selective) / candidate-then-verify
+        pos, sq, st = ctx.hits_host(both, s.codes, s.profile, thr_seq=thr, thr_struct=-3.0)
+        want = oracle.stream_hits(want_seq, want_st, thr, -3.0)
+        assert want.size > 10_000
+        assert np.array_equal(pos, want)
+        assert_f32_bits_equal(sq, want_seq[want])
+        assert_struct_close(st, want_st[want])
+    both.close()
