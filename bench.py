@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--mode", choices=["scores", "hits", "hits2"], default="scores",
                     help="scores: all-scores (the headline, 41.1 B/window); hits: thresholded hits, one fused pass "
                          "(29.1 B/window + 20 B/hit); hits2: candidate-then-verify (letters pass, structure only at its hits)")
+    ap.add_argument("--profile-dtype", choices=["float32", "float64"], default="float32",
+                    help="device storage of the profile rows (float32 = the headline, 41.1 B/window; float64 = the strict "
+                         "variant of SURVEY 8d, 69.2 B/window)")
     ap.add_argument("--minscore", type=float, default=6.0, help="threshold of --mode hits (seq > m and struct > m)")
     args = ap.parse_args()
 
@@ -151,6 +154,10 @@ def main():
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank,
                                         foreign=0.001 if args.variant == "inf" else 0.0,
                                         zero_snap=args.variant == "inf")
+    ptype = _lib.PROFILE_F32
+    if args.profile_dtype == "float64":
+        profile = profile.double()
+        ptype = _lib.PROFILE_F64
     # zero-filled (touched) outputs: first-touch of fresh device pages would otherwise
     # land in the first kernel launches and skew the per-kernel average rocprof reports
     out_seq = torch.zeros(n_pos, dtype=torch.float32, device=dev)
@@ -175,20 +182,20 @@ def main():
         if library:
             for mo in library:
                 hit_count.zero_()
-                ctx.hits_adaptive_dev(mo, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, args.minscore,
+                ctx.hits_adaptive_dev(mo, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, args.minscore,
                                       args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
                                       hit_count.data_ptr(), stream)
             return
         if args.mode in ("hits", "hits2"):
             hit_count.zero_()
             (ctx.hits_dev if args.mode == "hits" else ctx.hits_adaptive_dev)(motif, codes.data_ptr(), None if seq_only else profile.data_ptr(),
-                         _lib.PROFILE_NONE if seq_only else _lib.PROFILE_F32, n_pos, args.minscore,
+                         _lib.PROFILE_NONE if seq_only else ptype, n_pos, args.minscore,
                          args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
                          hit_count.data_ptr(), stream)
         elif seq_only:
             ctx.scan_dev(motif, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, out_seq.data_ptr(), None, stream)
         else:
-            ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos,
+            ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), ptype, n_pos,
                          out_seq.data_ptr(), out_st.data_ptr(), stream)
 
     def barrier():
@@ -221,7 +228,7 @@ def main():
     result = None
     if rank == 0:
         total_windows = windows * world * args.steps * (len(library) if library else 1)
-        in_b, out_b, hit_b = (1, 4, 12) if seq_only else (29, 12, 20)
+        in_b, out_b, hit_b = (1, 4, 12) if seq_only else (29 if ptype == _lib.PROFILE_F32 else 57, 12, 20)
         alg_bytes = args.records * args.length * in_b + windows * out_b      # per launch, per GPU
         n_hits = None
         if args.mode != "scores":
@@ -230,7 +237,7 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and args.mode == "scores":
+        if os.path.exists(tfile) and args.mode == "scores" and args.profile_dtype == "float32":
             try:
                 for tj in json.load(open(tfile)).get("entries", []):
                     if (tj.get("workload") == args.workload and tj.get("records") == args.records
@@ -259,8 +266,8 @@ def main():
                             ("C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes"
                              % (args.records, args.length, args.width)) if seq_only else
                             ("C3: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, "
-                             "uint8 codes + float32 [n][7] profile, all-scores (f32 seq + f64 struct per window)"
-                             % (args.records, args.length, args.width)),
+                             "uint8 codes + %s [n][7] profile, all-scores (f32 seq + f64 struct per window)"
+                             % (args.records, args.length, args.width, args.profile_dtype)),
                 "records_per_gpu": args.records, "record_length": args.length, "pfm_width": args.width,
                 "variant": args.variant, "settle_launches": args.settle, "windows_per_gpu_per_step": windows, "mode": "all-scores" if args.mode == "scores" else "hits",
                 "minscore": None if args.mode == "scores" else args.minscore, "hits_per_step": n_hits,

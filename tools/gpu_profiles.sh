@@ -9,6 +9,7 @@ run() { name=$1; shift; echo "== $name: bench.py $*"; python3 bench.py "$@" 2>>$
 import json,sys; d=json.load(open('$OUT/$name.json')); print('   ms_per_step %.4f value %.4g %s' % (d['ms_per_step'], d['value'], d['unit']))"; }
 run bench_c3_default
 run bench_c3_variant_inf --variant inf --no-ref-structured --no-cpu-baseline
+run bench_c3_profile_f64 --profile-dtype float64 --no-ref-structured
 run bench_c3_hits --mode hits --no-cpu-baseline
 run bench_c3_hits_two_phase --mode hits2 --no-cpu-baseline
 run bench_c3_hits_two_phase_m2 --mode hits2 --minscore 2 --no-cpu-baseline
