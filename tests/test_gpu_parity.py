@@ -436,3 +436,45 @@ def test_host_hits_come_back_sorted_at_millions_of_hits(ctx, oracle):
         assert_f32_bits_equal(sq, want_seq[want])
         assert_struct_close(st, want_st[want])
     both.close()
+
+
+def test_integration_md_pwm_stub_runs_verbatim(tmp_path, golden):
+    """the `_pwm.py` drop-in printed in INTEGRATION.md section 2, executed as written (only the library path
+    filled in) in a fresh interpreter without torch: same float32 scores as the goldens, same exceptions"""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import REPO
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# rnascan/BioAddons/motifs/_pwm\.py.*?)```", text, re.S).group(1)
+    lib = os.path.join(REPO, "rnascan_amd", "libpfmscan.so")
+    assert "/path/to/rnascan_amd/libpfmscan.so" in block
+    (tmp_path / "_pwm.py").write_text(block.replace("/path/to/rnascan_amd/libpfmscan.so", lib))
+    cases = [{"sequence": c["sequence"], "matrix": c["matrix"]} for c in golden["pwm"][:6]]
+    (tmp_path / "cases.json").write_text(json.dumps(cases))
+    driver = (
+        "import json, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import _pwm\n"
+        "out = []\n"
+        "for c in json.load(open(%r)):\n"
+        "    M = np.array(c['matrix'], dtype=np.float64).reshape(-1, 4)\n"
+        "    out.append(_pwm.calculate(c['sequence'], M).view(np.uint32).tolist())\n"
+        "try:\n"
+        "    _pwm.calculate('ACGU', np.zeros((2, 3)))\n"
+        "    out.append('no error')\n"
+        "except ValueError as e:\n"
+        "    out.append('ValueError')\n"
+        "print(json.dumps(out))\n" % (str(tmp_path), str(tmp_path / "cases.json")))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    run = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    got = json.loads(run.stdout.strip().splitlines()[-1])
+    assert got[-1] == "ValueError"
+    for bits, case in zip(got[:-1], golden["pwm"][:6]):
+        want = np.array(case["scores"], dtype=np.float32).view(np.uint32)
+        have = np.array(bits, dtype=np.uint32)
+        nan = np.isnan(want.view(np.float32))
+        assert np.array_equal(np.isnan(have.view(np.float32)), nan) and np.array_equal(have[~nan], want[~nan])
