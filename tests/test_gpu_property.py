@@ -1,5 +1,7 @@
 """Property-based parity (hypothesis): random ragged record sets, widths, alphabets, thresholds and
 PSSMs with -inf / +inf / NaN cells through the C ABI against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -41,7 +43,7 @@ def cases(draw):
     return pack.pack(codes, profs, profile_dtype=dtype), T, P, m, thr
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("PFMSCAN_HYPOTHESIS_EXAMPLES", "60")), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(case=cases())
 def test_random_streams_match_the_oracle(ctx, oracle, case):
     s, T, P, m, thr = case
