@@ -182,3 +182,22 @@ def test_cli_two_processes_one_gpu(tmp_path):
     assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
     assert open(tmp_path / "out.1.tsv").read() == ""
     assert single.getvalue().count("\n") > 50
+
+
+def test_cli_batches_do_not_change_the_table(engine, tmp_path, monkeypatch):
+    """RNASCAN_BATCH_POSITIONS small enough to cut a FASTA into many launches: same bytes out"""
+    from rnascan_amd import cli
+    rng = np.random.default_rng(5)
+    fa = tmp_path / "many.fa"
+    with open(fa, "w") as f:
+        for i in range(60):
+            L = int(rng.integers(0, 500))
+            f.write(">s%d some text\n%s\n" % (i, "".join(rng.choice(list("ACGTN"), size=L, p=[.24, .24, .24, .24, .04]))))
+    argv = ["-p", SEQ_PFM, "-u", "-C", "0.01", "-m", "-3", str(fa)]
+    whole = io.StringIO()
+    cli.main(argv, engine=engine, out=whole)
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "900")
+    cut = io.StringIO()
+    cli.main(argv, engine=engine, out=cut)
+    assert whole.getvalue().count("\n") > 50
+    assert cut.getvalue() == whole.getvalue()
