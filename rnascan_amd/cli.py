@@ -112,11 +112,12 @@ def load_motif(pfm_file, pseudocount, letters, background):
     return motifs_set
 
 
-def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None)):
+def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=None):
     """rnascan.py:335-413: `source` is a FASTA path, a directory of averaged
     structures, or a fasta.Record (the -t test sequence).  With more than one rank
     (dist_ctx = (rank, world, torch.distributed)) every rank scans its contiguous
-    share of the records and rank 0 receives the whole table (others get None)."""
+    share of the records and rank 0 receives the whole table (others get None).  With one rank
+    and a ``sink`` the batches' tables go to ``sink(frame)`` one by one and None is returned."""
     rank, world, dist = dist_ctx
     ptype = np.dtype(args.profile_dtype).type
     if isinstance(source, fasta.Record):
@@ -133,7 +134,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None)):
         df = shard.scan_sharded(ids, ps.lengths,
                                 lambda part: scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing,
                                                                 part[0] if part else 0, part[-1] + 1 if part else 0),
-                                rank, world, dist)
+                                rank, world, dist, sink=sink)
         fasta.eprint("Processed %d sequences" % len(ps.ids))
         return df
     if os.path.isdir(source):
@@ -143,14 +144,14 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None)):
             raise IOError("No averaged structure files found")
         df = shard.scan_sharded(named, [p.shape[0] for _, _, p in named],
                                 lambda part: scanner.scan_profiles(engine, part, pssm, args.minscore, args.pairing, ptype),
-                                rank, world, dist)
+                                rank, world, dist, sink=sink)
         fasta.eprint("Processed %d sequences" % len(named))
         return df
     fasta.eprint("Scanning sequences ")
     recs = list(fasta.parse_sequences(source))
     df = shard.scan_sharded(recs, [len(r.seq) for r in recs],
                             lambda part: scanner.scan_records(engine, part, pssm, letters, args.minscore),
-                            rank, world, dist)
+                            rank, world, dist, sink=sink)
     fasta.eprint("Processed %d sequences" % len(recs))
     return df
 
@@ -220,6 +221,19 @@ def main(argv=None, engine=None, out=None):
     rank, world, dist = dist_ctx
     eng = get_engine()
     final = None
+    # One rank and one table (no join): every batch is written as soon as it is scanned -- same bytes,
+    # Match_ID numbered across batches (rnascan.py:329-332) -- and never held as a whole.
+    writer = [None]
+
+    def stream_to(columns):
+        writer[0] = table.TsvWriter(out, columns, match_id=True)
+
+        def sink(frame):
+            if frame is not None and len(frame):
+                writer[0].write_chunk({c: frame[c].to_numpy() for c in writer[0].columns}, len(frame))
+        return sink
+
+    streaming = world == 1 and not args.testseq
     if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
         # sequence FASTA + averaged-structure directory: one fused kernel pass (config 3)
         ptype = np.dtype(args.profile_dtype).type
@@ -240,7 +254,7 @@ def main(argv=None, engine=None, out=None):
                 recs, [len(r.seq) for r in recs],
                 lambda part: scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore,
                                                    args.pairing, ptype),
-                rank, world, dist)
+                rank, world, dist, sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
         else:                                  # ids / lengths do not pair one to one: two tables + join
             seq_results = shard.scan_sharded(
                 recs, [len(r.seq) for r in recs],
@@ -252,10 +266,13 @@ def main(argv=None, engine=None, out=None):
             if rank == 0:
                 final = scanner.combine(seq_results, struct_results)
     else:
+        one_table = streaming and seq_type in ("RNA", "SS")
         if seq_type in ("RNA", "RNASS"):
-            seq_results = scan_main(eng, seq_source, seq_pssm, fasta.RNA, args, dist_ctx)
+            seq_results = scan_main(eng, seq_source, seq_pssm, fasta.RNA, args, dist_ctx,
+                                    sink=stream_to(scanner.SEQ_COLUMNS) if one_table else None)
         if seq_type in ("SS", "RNASS"):
-            struct_results = scan_main(eng, struct_source, struct_pssm, fasta.STRUCT, args, dist_ctx)
+            struct_results = scan_main(eng, struct_source, struct_pssm, fasta.STRUCT, args, dist_ctx,
+                                       sink=stream_to(scanner.SEQ_COLUMNS) if one_table else None)
         if rank == 0:
             if seq_type == "RNASS":
                 final = scanner.combine(seq_results, struct_results)
@@ -264,7 +281,7 @@ def main(argv=None, engine=None, out=None):
             else:
                 final = struct_results
 
-    if rank == 0:
+    if rank == 0 and writer[0] is None:
         # Match_ID 1..n after all filtering / joining (rnascan.py:329-332), then the same bytes as
         # DataFrame.to_csv(sep='\t', index=False) (:559-567), written chunk by chunk
         table.write_frame(out, final, match_id=True)

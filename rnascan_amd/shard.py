@@ -72,21 +72,28 @@ def batches(lengths, lo, hi, max_positions):
 
 
 def batch_positions():
-    """Stream positions one launch may hold (RNASCAN_BATCH_POSITIONS, default 2**28 = 268 M:
-    7.5 GB of float32 or 15 GB of float64 profile rows on the device and in the packed host copy).
-    Larger inputs go through several launches; the tables are concatenated in record order."""
-    return max(1, int(os.environ.get("RNASCAN_BATCH_POSITIONS", str(1 << 28))))
+    """Stream positions one launch may hold (RNASCAN_BATCH_POSITIONS, default 2**24 = 16.8 M:
+    0.94 GB of float64 profile rows on the device and in the packed host copy, and at most that many
+    table rows in memory at `-m ' -inf'`).  Larger inputs go through several launches (a launch + its
+    read-back cost well under a millisecond); the tables are written / concatenated in record order."""
+    return max(1, int(os.environ.get("RNASCAN_BATCH_POSITIONS", str(1 << 24))))
 
 
-def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None, max_positions=None):
+def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None, max_positions=None, sink=None):
     """Run ``scan_fn`` over this rank's contiguous range -- one call per batch of at
     most ``max_positions`` stream positions -- and gather the tables on rank 0.
     ``items`` is any sliceable list (records, profiles or pairs of them), ``lengths``
-    their lengths."""
+    their lengths.  With one rank and a ``sink`` every batch's table is handed to
+    ``sink(frame)`` as soon as it exists and nothing is kept (returns None): the hit
+    table never has to fit in memory."""
     if rank is None or world is None:
         rank, world = env_rank_world()
     lo, hi = partition(lengths, world)[rank]
     parts = batches(lengths, lo, hi, max_positions or batch_positions())
+    if sink is not None and world == 1:
+        for a, b in parts:
+            sink(scan_fn(items[a:b]))
+        return None
     frames = [scan_fn(items[a:b]) for a, b in parts]
     if len(frames) == 1:
         local = frames[0]
