@@ -127,3 +127,19 @@ def test_batched_scan_equals_one_launch(monkeypatch):
     cut = shard.scan_sharded(recs, [len(r.seq) for r in recs], fn2, rank=0, world=1)
     assert len(calls) > 5 and sum(calls) == len(recs)
     pd.testing.assert_frame_equal(whole.reset_index(drop=True), cut.reset_index(drop=True))
+
+
+def test_sink_receives_the_batches_in_order(monkeypatch):
+    """one rank + sink: nothing is returned, the batches' tables arrive one by one, in record order"""
+    from engines import OracleEngine
+    from rnascan_amd import fasta, scanner, shard
+    recs, P = _make_inputs()
+    eng = OracleEngine()
+    fn = lambda part: scanner.scan_records(eng, part, P, fasta.RNA, -2.0)   # noqa: E731
+    whole = shard.scan_sharded(recs, [len(r.seq) for r in recs], fn, rank=0, world=1)
+    got = []
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "1500")
+    ret = shard.scan_sharded(recs, [len(r.seq) for r in recs], fn, rank=0, world=1, sink=got.append)
+    assert ret is None and len(got) > 3
+    cat = pd.concat([g for g in got if len(g)], ignore_index=True)
+    pd.testing.assert_frame_equal(whole.reset_index(drop=True), cat)
