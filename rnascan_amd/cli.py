@@ -139,13 +139,23 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         return df
     if os.path.isdir(source):
         fasta.eprint("Scanning averaged secondary structures ")
-        named = scanner.load_profile_dir(source)
-        if len(named) == 0:
+        files = fasta.list_profiles(source)
+        if len(files) == 0:
             raise IOError("No averaged structure files found")
-        df = shard.scan_sharded(named, [p.shape[0] for _, _, p in named],
-                                lambda part: scanner.scan_profiles(engine, part, pssm, args.minscore, args.pairing, ptype),
-                                rank, world, dist, sink=sink)
-        fasta.eprint("Processed %d sequences" % len(named))
+        # the profiles of a batch are parsed when the batch is scanned, so only one batch of them is in memory;
+        # ranks and batches are balanced by file size (a text row is ~130 bytes: size / 64 over-estimates the
+        # positions, which only makes the batches smaller than they may be)
+        weights = [os.path.getsize(path) // 64 + 1 for _, path in files]
+
+        def scan_files(part):
+            named = []
+            for sid, path in part:
+                file_letters, prof = fasta.read_profile(path)
+                named.append((sid, file_letters, prof))
+            return scanner.scan_profiles(engine, named, pssm, args.minscore, args.pairing, ptype)
+
+        df = shard.scan_sharded(files, weights, scan_files, rank, world, dist, sink=sink)
+        fasta.eprint("Processed %d sequences" % len(files))
         return df
     fasta.eprint("Scanning sequences ")
     recs = list(fasta.parse_sequences(source))
