@@ -43,7 +43,10 @@ def cases(draw):
     return pack.pack(codes, profs, profile_dtype=dtype), T, P, m, thr
 
 
-@settings(max_examples=int(os.environ.get("PFMSCAN_HYPOTHESIS_EXAMPLES", "60")), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+# the default run replays the same 60 examples every time (derandomize); an exploration run sets
+# PFMSCAN_HYPOTHESIS_EXAMPLES (and --hypothesis-seed) and draws fresh ones
+@settings(max_examples=int(os.environ.get("PFMSCAN_HYPOTHESIS_EXAMPLES", "60")), deadline=None,
+          derandomize="PFMSCAN_HYPOTHESIS_EXAMPLES" not in os.environ, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(case=cases())
 def test_random_streams_match_the_oracle(ctx, oracle, case):
     s, T, P, m, thr = case
