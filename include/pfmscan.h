@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 1
+#define PFMSCAN_ABI_VERSION 2
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -187,6 +187,61 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                         double thr_seq, double thr_struct, int64_t capacity,
                         int64_t *hit_pos, float *hit_seq, double *hit_struct,
                         int64_t *n_hits);
+
+/* ---- multi-PFM libraries: every motif in ONE pass (BASELINE config 5) ----------
+ * The reference loads one PFM file per run (load_motif, rnascan.py:217-218), scans only the first
+ * motif of its dict (rnascan.py:262) and would re-read every sequence and profile per motif,
+ * although it ships a multi-PFM format (pfmutil.py:89-133).  A library object holds n motifs of one
+ * width m:
+ *   letter_tables  double [n][m][8], each as in pfmscan_motif_create; the alphabet must be the 4 codes
+ *                  0..3 (columns 4..7 NaN) -- otherwise PFMSCAN_E_BADSHAPE, scan such motifs one by one
+ *   struct_pssms   double [n][m][7] or NULL: motif k's structure PSSM, paired with letter table k
+ * Hit of motif k at window p (same filter as pfmscan_hits_dev, per motif):
+ *   seq_k(p) > thr_seq[k]  and  (no structure PSSMs or struct_k(p) > thr_struct[k])
+ * i.e. pssm.search's strict `>` (rnascan.py:263), `score > minscore` (:310) and combine()'s inner
+ * join (:422-423) for the pair (sequence motif k, structure motif k).  Scores are the same numbers the
+ * single-motif entry points give (float32 of the sequential fp64 sum; fp64 per-row nan_to_num sum).
+ * thr_seq / thr_struct are HOST arrays of n doubles; thr_seq must be > -inf (at -inf every window is a hit:
+ * use the all-scores entry points). */
+typedef struct pfmscan_library pfmscan_library;
+int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables,
+                           const double *struct_pssms, int n_motifs, int m,
+                           pfmscan_library **out);
+void pfmscan_library_destroy(pfmscan_library *lib);
+/* passes the library needs (motifs that fit the 160 KB of LDS at once), the largest one-sided slack of the
+ * integer prefilter at the last thresholds in score units (NaN before the first scan, inf when a motif with
+ * +inf / NaN log-odds sums runs without prefilter); any pointer may be NULL */
+int pfmscan_library_info(const pfmscan_library *lib, int *n_motifs, int *m, int *n_passes,
+                         int *motifs_per_pass, double *max_eps);
+/* Device-resident form, asynchronous on `stream`.  Hits in no particular order:
+ *   d_hit_pos int64 [capacity], d_hit_motif int32 [capacity] (motif index 0..n-1),
+ *   d_hit_seq float [capacity] or NULL, d_hit_struct double [capacity] or NULL,
+ *   d_hit_count: one uint64 (need not be zeroed); afterwards the TOTAL number of hits.  A value
+ *   above capacity means the hit arrays are incomplete: call again with at least that capacity. */
+int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib,
+                             const uint8_t *d_codes, const void *d_profile,
+                             int profile_dtype, int64_t n_pos, const double *thr_seq,
+                             const double *thr_struct, int64_t capacity,
+                             int64_t *d_hit_pos, int32_t *d_hit_motif, float *d_hit_seq,
+                             double *d_hit_struct, uint64_t *d_hit_count, void *stream);
+/* Staged / host-buffer forms (see pfmscan_stage): hits come back sorted by (position, motif index).
+ * PFMSCAN_E_CAPACITY: *n_hits holds a capacity that suffices, nothing was written. */
+int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib,
+                                const double *thr_seq, const double *thr_struct,
+                                int64_t capacity, int64_t *hit_pos, int32_t *hit_motif,
+                                float *hit_seq, double *hit_struct, int64_t *n_hits);
+int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib,
+                              const uint8_t *codes, const void *profile, int profile_dtype,
+                              int64_t n_pos, const double *thr_seq, const double *thr_struct,
+                              int64_t capacity, int64_t *hit_pos, int32_t *hit_motif,
+                              float *hit_seq, double *hit_struct, int64_t *n_hits);
+
+/* Diagnostics (host only, no device needed): the unsigned 16-bit two-letter credit table the library kernel's
+ * prefilter uses for ONE motif (letter_table double [m][8], 4-letter alphabet) at threshold thr_seq:
+ * credits uint16 [ceil(m/2)][16], entry index c0 | c1 << 2.  A window whose credits sum modulo 65536 has bit 15
+ * clear cannot be a hit; *slack = how far below the threshold a kept window's score may lie (score units). */
+int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq,
+                               uint16_t *credits, double *slack);
 
 /* ---- measurement helper ------------------------------------------------------
  * Average device time in milliseconds of `iters` back-to-back pfmscan_scan_dev

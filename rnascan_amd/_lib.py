@@ -21,7 +21,7 @@ SEP = 7
 NCODE = 8
 NSTRUCT = 7
 MAX_M = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -30,6 +30,8 @@ SYMBOLS = [
     "pfmscan_pwm_calculate", "pfmscan_scan_dev", "pfmscan_scan_letters_f64_dev", "pfmscan_hits_dev",
     "pfmscan_scan_host", "pfmscan_scan_letters_f64_host", "pfmscan_hits_host", "pfmscan_time_scan_dev",
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
+    "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
+    "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
 ]
 
 
@@ -98,8 +100,17 @@ def load():
     L.pfmscan_scan_staged.argtypes = [vp, vp, vp, vp]
     L.pfmscan_hits_staged.argtypes = [vp, vp, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_time_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, i32, i32, ctypes.POINTER(dbl)]
+    L.pfmscan_library_create.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(vp)]
+    L.pfmscan_library_destroy.argtypes = [vp]
+    L.pfmscan_library_destroy.restype = None
+    L.pfmscan_library_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                       ctypes.POINTER(dbl)]
+    L.pfmscan_library_hits_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.pfmscan_library_hits_staged.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     for name in SYMBOLS:          # every other entry point returns a status
-        if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error"):
+        if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy"):
             getattr(L, name).restype = i32
     if L.pfmscan_abi_version() != ABI_VERSION:
         raise ImportError("libpfmscan ABI %d, bindings expect %d" % (L.pfmscan_abi_version(), ABI_VERSION))
@@ -191,6 +202,7 @@ class Context(object):
             raise MemoryError("failed to create output data")      # _pwm.c:26-31 on a negative shape
         out = np.empty(n, dtype=np.float32)
         self.scratch_gen += 1
+        self._staged_n = -1                 # the C side restages: a following scan_staged must not trust the old length
         self._check(self._L.pfmscan_pwm_calculate(self._h, seq, len(seq), _ptr(M), M.shape[0], _ptr(out)))
         return out
 
@@ -201,14 +213,17 @@ class Context(object):
         out_seq = np.empty(n, dtype=np.float32) if (want_seq and motif.has_letters) else None
         out_struct = np.empty(n, dtype=np.float64) if (want_struct and motif.has_struct) else None
         self.scratch_gen += 1
+        self._staged_n = -1
         self._check(self._L.pfmscan_scan_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n,
                                               _ptr(out_seq), _ptr(out_struct)))
+        self._staged_n = n                  # scan_host = stage + scan_staged: the stream stays staged
         return out_seq, out_struct
 
     def scan_letters_f64_host(self, motif, codes):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         out = np.empty(codes.size, dtype=np.float64)
         self.scratch_gen += 1
+        self._staged_n = -1
         self._check(self._L.pfmscan_scan_letters_f64_host(self._h, motif._h, _ptr(codes), codes.size, _ptr(out)))
         return out
 
@@ -218,6 +233,7 @@ class Context(object):
         n, codes, profile, dt = _stream_args(motif, codes, profile)
         cap = int(capacity) if capacity is not None else max(1024, n // 64)
         self.scratch_gen += 1
+        self._staged_n = -1
         while True:
             pos = np.empty(cap, dtype=np.int64)
             sq = np.empty(cap, dtype=np.float32)
@@ -231,6 +247,7 @@ class Context(object):
                 continue
             self._check(rc, k.value)
             k = int(k.value)
+            self._staged_n = n              # hits_host = stage + hits_staged: the stream stays staged
             return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
 
     # -- staged stream: upload once, run many motifs ------------------------------------
@@ -263,6 +280,8 @@ class Context(object):
 
     def scan_staged(self, motif, want_seq=True, want_struct=True):
         n = self._staged_n
+        if n < 0:
+            raise ValueError("no stream staged (call stage first)")
         out_seq = np.empty(n, dtype=np.float32) if (want_seq and motif.has_letters) else None
         out_struct = np.empty(n, dtype=np.float64) if (want_struct and motif.has_struct) else None
         self._check(self._L.pfmscan_scan_staged(self._h, motif._h, _ptr(out_seq), _ptr(out_struct)))
@@ -270,6 +289,8 @@ class Context(object):
 
     def hits_staged(self, motif, thr_seq=-np.inf, thr_struct=-np.inf, capacity=None):
         n = self._staged_n
+        if n < 0:
+            raise ValueError("no stream staged (call stage first)")
         cap = int(capacity) if capacity is not None else max(1024, n // 64)
         while True:
             pos = np.empty(cap, dtype=np.int64)
@@ -284,6 +305,46 @@ class Context(object):
             self._check(rc, k.value)
             k = int(k.value)
             return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
+
+    # -- multi-PFM libraries (every motif in one pass) --------------------------------
+    def library(self, letter_tables, struct_pssms=None):
+        return Library(self, letter_tables, struct_pssms)
+
+    def library_hits_staged(self, lib, thr_seq, thr_struct=None, capacity=None):
+        """hits of every motif of ``lib`` over the staged stream, sorted by (position, motif index)
+        -> (pos int64[k], motif int32[k], seq float32[k], struct float64[k] | None)"""
+        n = self._staged_n
+        if n < 0:
+            raise ValueError("no stream staged (call stage first)")
+        ts, tt = lib.thresholds(thr_seq, thr_struct)
+        cap = int(capacity) if capacity is not None else max(4096, n // 16)
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            mo = np.empty(cap, dtype=np.int32)
+            sq = np.empty(cap, dtype=np.float32)
+            st = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_library_hits_staged(self._h, lib._h, _ptr(ts), _ptr(tt), cap, _ptr(pos), _ptr(mo),
+                                                     _ptr(sq), _ptr(st), ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
+            return pos[:k].copy(), mo[:k].copy(), sq[:k].copy(), (st[:k].copy() if lib.has_struct else None)
+
+    def library_hits_host(self, lib, codes, profile=None, thr_seq=None, thr_struct=None, capacity=None):
+        self.stage(codes, profile if lib.has_struct else None)
+        return self.library_hits_staged(lib, thr_seq, thr_struct, capacity)
+
+    def library_hits_dev(self, lib, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity,
+                         d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct, d_hit_count, stream=None):
+        """asynchronous on ``stream``; hits unordered, *d_hit_count = total (above capacity = incomplete)"""
+        ts, tt = lib.thresholds(thr_seq, thr_struct)
+        self._check(self._L.pfmscan_library_hits_dev(self._h, lib._h, _ptr(d_codes), _ptr(d_profile), int(profile_dtype),
+                                                     int(n_pos), _ptr(ts), _ptr(tt), int(capacity), _ptr(d_hit_pos),
+                                                     _ptr(d_hit_motif), _ptr(d_hit_seq), _ptr(d_hit_struct),
+                                                     _ptr(d_hit_count), _ptr(stream)))
 
     # -- device-pointer scans (pointers are ints, e.g. torch data_ptr()) ----------
     def scan_dev(self, motif, d_codes, d_profile, profile_dtype, n_pos, d_out_seq, d_out_struct, stream=None):
@@ -350,6 +411,72 @@ class Motif(object):
             self.close()
         except Exception:
             pass
+
+
+class Library(object):
+    """n motifs of one width resident on the device for one-pass scans:
+    letter_tables [n][m][8] (4-letter alphabet), struct_pssms [n][m][7] or None."""
+
+    def __init__(self, ctx, letter_tables, struct_pssms=None):
+        self._ctx = ctx
+        self._L = ctx._L
+        lt = np.ascontiguousarray(letter_tables, dtype=np.float64)
+        if lt.ndim != 3 or lt.shape[2] != NCODE:
+            raise ValueError("letter_tables must be [n][m][8]")
+        sp = None
+        if struct_pssms is not None:
+            sp = np.ascontiguousarray(struct_pssms, dtype=np.float64)
+            if sp.shape != (lt.shape[0], lt.shape[1], NSTRUCT):
+                raise ValueError("struct_pssms must be [n][m][7] with the letter tables' n and m")
+        self.n, self.m = int(lt.shape[0]), int(lt.shape[1])
+        self.has_struct = sp is not None
+        h = ctypes.c_void_p()
+        ctx._check(self._L.pfmscan_library_create(ctx._h, _ptr(lt), _ptr(sp), self.n, self.m, ctypes.byref(h)))
+        self._h = h
+
+    def thresholds(self, thr_seq, thr_struct=None):
+        """scalars or per-motif arrays -> float64 [n] arrays (None for the structure side of a sequence-only library)"""
+        ts = np.ascontiguousarray(np.broadcast_to(np.asarray(thr_seq, dtype=np.float64), (self.n,)))
+        tt = None
+        if self.has_struct:
+            tt = np.ascontiguousarray(np.broadcast_to(np.asarray(-np.inf if thr_struct is None else thr_struct,
+                                                                 dtype=np.float64), (self.n,)))
+        return ts, tt
+
+    def info(self):
+        n, m, npass, per, eps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        self._ctx._check(self._L.pfmscan_library_info(self._h, ctypes.byref(n), ctypes.byref(m), ctypes.byref(npass),
+                                                      ctypes.byref(per), ctypes.byref(eps)))
+        return {"n_motifs": n.value, "m": m.value, "passes": npass.value, "motifs_per_pass": per.value,
+                "max_prefilter_eps": eps.value}
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._L.pfmscan_library_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def credit_table(letter_table, thr_seq):
+    """Host-only diagnostic (no device needed): the unsigned 16-bit two-letter credit table the library kernel's
+    prefilter uses for ONE motif at threshold ``thr_seq`` -> (credits uint16 [ceil(m/2)][16], slack in score units).
+    A window whose credits sum (mod 65536) has bit 15 clear cannot be a hit; tests check that exhaustively."""
+    L = load()
+    T = np.ascontiguousarray(letter_table, dtype=np.float64)
+    if T.ndim != 2 or T.shape[1] != NCODE:
+        raise ValueError("letter_table must be [m][8]")
+    m = T.shape[0]
+    out = np.zeros(((m + 1) // 2, 16), dtype=np.uint16)
+    slack = ctypes.c_double(0.0)
+    rc = L.pfmscan_debug_credit_table(_ptr(T), m, float(thr_seq), _ptr(out), ctypes.byref(slack))
+    if rc != OK:
+        raise ValueError("pfmscan_debug_credit_table: bad argument")
+    return out, slack.value
 
 
 def _stream_args(motif, codes, profile):

@@ -11,8 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpfmscan.so")
-SOURCES = ["pfmscan_kernels.hip", "pfmscan_api.hip", "pfmscan_sort.hip"]
-DEPS = SOURCES + ["pfmscan_internal.hpp", os.path.join("..", "..", "include", "pfmscan.h")]
+SOURCES = ["pfmscan_kernels.hip", "pfmscan_api.hip", "pfmscan_sort.hip", "pfmscan_library.hip", "pfmscan_library_api.hip"]
+DEPS = SOURCES + ["pfmscan_internal.hpp", "pfmscan_ctx.hpp", os.path.join("..", "..", "include", "pfmscan.h")]
 
 
 def hipcc_path():

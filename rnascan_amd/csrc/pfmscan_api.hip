@@ -12,33 +12,9 @@
 #include <string>
 #include <vector>
 
-#include "pfmscan_internal.hpp"
+#include "pfmscan_ctx.hpp"
 
 using namespace pfmscan;
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct pfmscan_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    Tuning tune;
-    int n_cu = 0;
-    int64_t hbm = 0;
-    char name[128] = {0};
-    DevBuf codes, profile, out_seq, out_struct, hit_pos, hit_seq, hit_struct, count, table;
-    DevBuf cand_pos, cand_seq, cand_count;      // candidates of the two-phase combined scan
-    DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, sort_seq, sort_struct;   // pfmscan_sort.hip
-    // staged stream (pfmscan_stage)
-    int64_t staged_n = -1;
-    int staged_dtype = PFMSCAN_PROFILE_NONE;
-    bool staged_codes = false, staged_profile = false;
-    // candidate-then-verify: the last full letters pass was selective -> skip the pilot next time
-    bool two_phase_hot = false;
-};
 
 struct pfmscan_motif {
     pfmscan_ctx *ctx = nullptr;
@@ -52,25 +28,21 @@ struct pfmscan_motif {
 
 static thread_local std::string g_err;
 
-static int fail(pfmscan_ctx *ctx, int code, const std::string &msg)
+namespace pfmscan {
+
+int fail(pfmscan_ctx *ctx, int code, const std::string &msg)
 {
     if (ctx) ctx->err = msg; else g_err = msg;
     return code;
 }
 
-static int fail_hip(pfmscan_ctx *ctx, hipError_t e, const char *what)
+int fail_hip(pfmscan_ctx *ctx, hipError_t e, const char *what)
 {
     std::string msg = std::string(what) + ": " + hipGetErrorString(e);
     return fail(ctx, e == hipErrorOutOfMemory ? PFMSCAN_E_OOM : PFMSCAN_E_HIP, msg);
 }
 
-#define HIP_TRY(ctx, expr)                                         \
-    do {                                                           \
-        hipError_t e__ = (expr);                                   \
-        if (e__ != hipSuccess) return fail_hip((ctx), e__, #expr); \
-    } while (0)
-
-static int ensure(pfmscan_ctx *ctx, DevBuf &b, size_t bytes)
+int ensure(pfmscan_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return PFMSCAN_OK;
     if (b.p) {
@@ -88,14 +60,14 @@ static int ensure(pfmscan_ctx *ctx, DevBuf &b, size_t bytes)
     return PFMSCAN_OK;
 }
 
-static void release(DevBuf &b)
+void release(DevBuf &b)
 {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
 }
 
-static bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+}  // namespace pfmscan
 
 extern "C" {
 
@@ -147,10 +119,15 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
     for (DevBuf *b : {&ctx->codes, &ctx->profile, &ctx->out_seq, &ctx->out_struct, &ctx->hit_pos,
                       &ctx->hit_seq, &ctx->hit_struct, &ctx->count, &ctx->table, &ctx->cand_pos, &ctx->cand_seq,
                       &ctx->cand_count, &ctx->sort_keys_in, &ctx->sort_keys_out, &ctx->sort_vals_in, &ctx->sort_vals_out,
-                      &ctx->sort_temp, &ctx->sort_seq, &ctx->sort_struct})
+                      &ctx->sort_temp, &ctx->sort_seq, &ctx->sort_struct, &ctx->hit_motif, &ctx->sort_motif, &ctx->lib_pos,
+                      &ctx->lib_motif, &ctx->lib_seq, &ctx->lib_struct, &ctx->lib_count})
         release(*b);
     delete ctx;
 }

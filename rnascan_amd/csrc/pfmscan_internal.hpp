@@ -80,7 +80,48 @@ struct GatherArgs {
     size_t temp_bytes;                    // >= sort_temp_bytes(total, key_bits)
     float *seq_out;                       // [total]
     double *struct_out;                   // [total]
+    // library scans: motif index per hit, sorted with the hits; key = pos << motif_bits | motif
+    const int32_t *hit_motif = nullptr;   // may be null
+    int32_t *motif_out = nullptr;         // [total]
+    int motif_bits = 0;
 };
+
+// ---- multi-PFM library scan (pfmscan_library.hip) ------------------------------------------------------
+// one workgroup per CU, its waves independent and sharing the LDS tables: 16 waves (128 VGPRs each) for PFMs up to
+// width 32, 8 waves (256 VGPRs) for the widest bucket, whose 32 pair addresses per lane would otherwise spill
+__host__ __device__ constexpr int lib_block(int np_bucket) { return np_bucket > 16 ? 512 : 1024; }
+constexpr int LIB_QCAP = 128;             // (window, motif octet) items a wave can park (>= 64 + 63)
+constexpr int LIB_SHARDS = 256;           // sharded hit buffers of a library scan: workgroup b appends to shard b & 255
+
+struct LibArgs {
+    const uint8_t *codes;                 // [n_pos]
+    const void *profile;                  // [n_pos][7] or null (sequence-only library)
+    int profile_dtype;
+    int64_t n_pos;                        // stream length (bounds of every read)
+    int64_t pos_base, span;               // this launch scores the windows starting in [pos_base, pos_base + span), span < 2^32
+    int64_t seg_positions, n_seg;         // work split: segment s (seg_positions windows, multiple of 1024) -> workgroup s mod grid
+    // one pass = nmp = 8 * ng motifs, tables laid out for the kernel (pfmscan_library_api.hip builds them)
+    const uint32_t *pairs;                // [npair][ng][16][8] u16 two-letter credits, threshold folded into pair row 0
+    const double *letters;                // [m * 4][nmp] fp64, transposed
+    const double *pssm;                   // [m * 7][nmp] fp64, transposed; null = no structure side
+    const double *thr_seq, *thr_struct;   // [nmp]
+    int m, npair, nmp, ng, motif_base;
+    // hits: LIB_SHARDS (or 1) regions of shard_cap slots, counters HIT_COUNTER_STRIDE words apart
+    int64_t shard_cap;
+    int hit_shards;
+    int64_t *hit_pos;
+    int32_t *hit_motif;
+    float *hit_seq;
+    double *hit_struct;
+    unsigned long long *hit_count;
+};
+size_t lib_motif_bytes(int m, int npair, bool has_struct);     // LDS bytes per motif of a pass
+size_t lib_queue_bytes(int np_bucket);                          // LDS bytes of the wave queues
+size_t lib_lds_bytes(int m, int npair, int nmp, bool has_struct, int np_bucket);
+int lib_np_bucket(int m);
+int lib_pick_ng(int np_bucket, int want_octets, int max_octets);   // supported octet count of a pass (0: none fits)
+hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream);
+
 hipError_t sort_temp_bytes(int64_t total, int key_bits, size_t *bytes);
 hipError_t launch_gather_sorted(const GatherArgs &g, hipStream_t stream);
 

@@ -1,0 +1,487 @@
+// pfmscan_library.hip -- all motifs of a PFM library in ONE pass over the stream (BASELINE
+// config 5: 256 seq+struct PFM pairs x 100k x 3 kb).  gfx950, wave64, one 1024-thread workgroup per CU.
+//
+// The reference scans one PFM per run (rnascan.py:217-218, :262) although it ships a multi-PFM format
+// (pfmutil.py:89-133).  A hit of motif k at window p needs seq_k(p) > thr_seq[k] (pssm.search, rnascan.py:263,
+// strict) AND struct_k(p) > thr_struct[k] (rnascan.py:310), the inner join of combine() (rnascan.py:422-423).
+//
+// Per motif-window the letters side costs ceil(m/2) table look-ups, so a library scan is bound by LDS look-up
+// and VALU issue rate, not by HBM (the codes are read once for all motifs of a pass).  Design:
+//
+//  phase A (every window x every motif): "can this window be a hit?" from two-letter CREDIT tables: unsigned
+//      16-bit fixed point, EIGHT motifs interleaved per 16-byte entry ([pair row][octet][16 entries][8 motifs] in
+//      LDS) -> one ds_read_b128 per (window, pair row, 8 motifs), two motifs per 32-bit add, two rows per
+//      v_add3_u32.  Integer adds are exact and the host rounds every credit UP (pfmscan_library_api.hip), so the
+//      test can only err towards keeping a window.  The threshold is folded into pair row 0 so that "may be a
+//      hit" is "bit 15 set": an OR over the four accumulator registers tests 8 motifs at once.  A lane owns ONE
+//      window; its pair offsets are computed once per window and serve every octet, and because the octet count
+//      NG is a template parameter every table offset is an immediate of the ds_read.  Windows covering a
+//      foreign letter or separator are dropped here (their exact score is NaN, _pwm.c:61-66).
+//  queue: a flagged (window, motif octet) goes to the wave's private LDS queue (position, octet, flag bits, the
+//      window's letters as 2-bit codes): no atomics, waves never synchronise with each other.
+//  phase B (dense, once 64 items wait): one item per lane.  The exact score is the sequential fp64 sum of
+//      _pwm.c:34-68 from an LDS copy of the fp64 letter tables, cast to float32 and compared with the threshold --
+//      only that decides.  A window that passes gets the exact structure score of rnascan.py:302-307
+//      (per-row nan_to_num, fp64): rows straight from global memory (the neighbours of a wave's windows are in
+//      L1/L2), the motif's PSSM from LDS.  Hits are compacted inside the wave; one returning atomic per batch on
+//      one of 256 sharded counters.
+//
+// LDS per motif at width m: ceil(m/2)*32 B (credits) + m*32 B (fp64 letters) + m*56 B (fp64 structure PSSM)
+// + 16 B thresholds; a library larger than the 160 KB allow is scanned in several passes (256 pairs of width 12:
+// passes of 96 / 96 / 64 motifs), each re-reading only the 1-byte codes.
+#include <float.h>
+#include <math.h>
+
+#include "pfmscan_internal.hpp"
+
+namespace pfmscan {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const unsigned char *lds_cptr;
+
+__device__ __forceinline__ double lib_nan_to_num(double d)
+{
+    double c = fmin(fmax(d, -DBL_MAX), DBL_MAX);
+    return (d != d) ? 0.0 : c;
+}
+
+__device__ __forceinline__ lds_cptr lds_ptr_of(const void *p) { return (lds_cptr)p; }
+
+// 4 code bytes at the 4-byte-aligned stream position p; positions >= n_pos read as separators
+__device__ __forceinline__ uint32_t lib_codes4(const uint8_t *__restrict__ codes, int64_t p, int64_t n_pos)
+{
+    if (p + 4 <= n_pos) return *reinterpret_cast<const uint32_t *>(codes + p);
+    uint32_t w = 0x07070707u;
+    for (int b = 0; b < 4; ++b)
+        if (p + b < n_pos) w = (w & ~(0xFFu << (8 * b))) | ((uint32_t)codes[p + b] << (8 * b));
+    return w;
+}
+
+// structure score of the window at stream position p for pass-local motif mo: rows from global memory as
+// element-aligned 4-vectors (7 loads per 4 rows, see struct_score_at in pfmscan_kernels.hip), PSSM cells from the
+// transposed LDS copy pssm[(j*7+c)*NMP + mo] (neighbouring motifs 8 bytes apart: the distinct motifs of a wave
+// spread over the banks; NMP is a compile-time constant, so the cell offsets are immediates).
+template <typename PROF_T, int NMP>
+__device__ __forceinline__ double lib_struct_score(const void *profile, int64_t p, int m, const double *pssm_lds, int mo)
+{
+    typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+    const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(profile) + p * 7;
+    const double *P = pssm_lds + mo;
+    double score = 0.0;
+    for (int j0 = 0; j0 < m; j0 += 4) {
+        PROF_T val[28];
+        int base = j0;
+        if (m >= 4) {
+            base = j0 < m - 4 ? j0 : m - 4;
+            const PROF_T *r = prof + base * 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const v4_t q = *reinterpret_cast<const v4_t *>(r + 4 * k);
+                val[4 * k] = q[0];
+                val[4 * k + 1] = q[1];
+                val[4 * k + 2] = q[2];
+                val[4 * k + 3] = q[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base + u;
+            if (j >= j0 && j < m) {
+                const double *Pj = P + (size_t)j * 7 * NMP;
+                double d = (double)val[u * 7] * Pj[0];
+#pragma unroll
+                for (int c = 1; c < 7; ++c) d = fma((double)val[u * 7 + c], Pj[c * NMP], d);
+                score += lib_nan_to_num(d);
+            }
+        }
+    }
+    return score;
+}
+
+// Credits of one motif octet for the lane's window: K pair rows (compile-time), every look-up in flight before the
+// first add (8 rows at a time for wide PFMs), two rows per v_add3_u32.  rowp[t] points at the lane's entry of pair
+// row t in octet 0; `off` (bytes, = octet * 256) is an immediate when it is a constant.
+template <int K, int NP>
+__device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const int off)
+{
+    u32x4 acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t0 = 0; t0 < K; t0 += 8) {
+        u32x4 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (t0 + i < K) r[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(rowp[t0 + i] + off);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            if (t0 + i + 1 < K) {
+                acc.x = acc.x + r[i].x + r[i + 1].x;
+                acc.y = acc.y + r[i].y + r[i + 1].y;
+                acc.z = acc.z + r[i].z + r[i + 1].z;
+                acc.w = acc.w + r[i].w + r[i + 1].w;
+            } else if (t0 + i < K) {
+                acc.x += r[i].x;
+                acc.y += r[i].y;
+                acc.z += r[i].z;
+                acc.w += r[i].w;
+            }
+        }
+    }
+    return acc;
+}
+
+// flagged lanes of one octet -> the wave's queue.  mk = ballot of the flags (non-zero), qn = queue length.
+template <int NP>
+__device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const unsigned long long mk, const int qn, const int g,
+                                         const uint32_t relpos, const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs,
+                                         uint32_t *q_cw)
+{
+    if (flag) {
+        // flag bytes of the 8 accumulators: p0 = {x.lo, x.hi, y.lo, y.hi}, p1 = {z.lo, z.hi, w.lo, w.hi} (bit 7 of each
+        // byte = bit 15 of the credit sum); bits: byte b, bit 0 = motif 8g + b may be a hit, bit 1 = motif 8g + 4 + b
+        const uint32_t p0 = __builtin_amdgcn_perm(acc.y, acc.x, 0x07050301u);
+        const uint32_t p1 = __builtin_amdgcn_perm(acc.w, acc.z, 0x07050301u);
+        const uint32_t bits = ((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u);
+        const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        q_pos[slot] = relpos;
+        q_gs[slot] = bits | ((uint32_t)g << 2);           // g < 64 in bits 2-7 of byte 0
+#pragma unroll
+        for (int k = 0; k < NP / 8; ++k) q_cw[k * LIB_QCAP + slot] = cw[k];
+    }
+}
+
+// Phase A, fast path: all NG octets of the lane's window, fully unrolled (immediate table offsets).  Pushes while
+// the queue has room; returns the first octet that did NOT fit (NG when all did) -- from there the slow path takes
+// over after a drain.  A chunk brings ~1.3 items per octet at realistic thresholds, the queue takes >= 65.
+template <int K, int NG, int NP>
+__device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
+                                               const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs, uint32_t *q_cw)
+{
+    int g_next = NG;
+    int qs = __builtin_amdgcn_readfirstlane(qn);      // the queue length is wave-uniform: keep it (and the branches on it) scalar
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
+        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x80008000u) != 0u;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
+        if (mk && g_next == NG) {                     // wave-uniform
+            const int n = __popcll(mk);
+            // the bookkeeping first, in scalar registers, the (divergent) writes after it: behind the writes hipcc
+            // carries both values in VGPRs (selects and moves per octet)
+            const bool fits = qs + n <= LIB_QCAP;
+            const int at = qs;
+            g_next = fits ? NG : g;
+            qs = fits ? qs + n : qs;
+            asm volatile("" : "+s"(qs), "+s"(g_next));
+            if (fits) lib_push<NP>(acc, flag, mk, at, g, relpos, cw, q_pos, q_gs, q_cw);
+        }
+    }
+    qn = qs;
+    return g_next;
+}
+
+// Phase A, slow path: octets g .. NG-1 one by one (runtime table offset), stopping as soon as 64 items wait.
+// Needs qn < 64 on entry (an octet brings at most 64 items, the queue holds LIB_QCAP >= 127).
+template <int K, int NG, int NP>
+__device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
+                                               const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs, uint32_t *q_cw)
+{
+    int qs = __builtin_amdgcn_readfirstlane(qn);
+    g = __builtin_amdgcn_readfirstlane(g);
+    while (g < NG && qs < 64) {
+        const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
+        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x80008000u) != 0u;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
+        if (mk) {
+            lib_push<NP>(acc, flag, mk, qs, g, relpos, cw, q_pos, q_gs, q_cw);
+            qs += __popcll(mk);
+        }
+        ++g;
+    }
+    qn = qs;
+    return g;
+}
+
+// npair -> the K-row instantiation, over the pair counts of one width bucket (K = KLO .. NP)
+template <bool FAST, int K, int NG, int NP>
+__device__ __forceinline__ int lib_dispatch(const int npair, const int g, const lds_cptr (&rowp)[NP], int &qn,
+                                            const uint32_t relpos, const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs,
+                                            uint32_t *q_cw)
+{
+    if constexpr (K >= NP) {
+        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+    } else {
+        if (npair == K) {
+            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+        }
+        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+    }
+}
+
+// NG = motif octets of the pass, NP = pair rows the code is unrolled for (8 / 16 / 32 for m <= 16 / 32 / 64)
+template <int NG, int NP, typename PROF_T, bool HAS_STRUCT>
+__global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
+{
+    constexpr int LIB_BLOCK = lib_block(NP);
+    constexpr int LIB_WAVES = LIB_BLOCK / 64;
+    constexpr int NMP = NG * 8;                     // motifs of the pass (padding motifs never flag)
+    constexpr int CW = NP / 8;                      // dwords of 2-bit codes per window (16 letters each)
+    constexpr int NRAW = NP / 2 + 1;                // aligned code dwords a lane loads
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int m = a.m, npair = a.npair;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- LDS carve-up (same arithmetic as lib_lds_bytes) ----
+    const int pair_bytes = npair * NG * 256;        // + one all-zero row of NG * 256 bytes: row 0 of the windows that cannot score
+    uint32_t *pairs = reinterpret_cast<uint32_t *>(smem);
+    double *letters = reinterpret_cast<double *>(smem + pair_bytes + NG * 256);
+    double *pssm = letters + (size_t)m * 4 * NMP;
+    double *thr_s = pssm + (HAS_STRUCT ? (size_t)m * 7 * NMP : 0);
+    double *thr_t = thr_s + NMP;
+    uint32_t *qbase = reinterpret_cast<uint32_t *>(thr_t + NMP);
+    uint32_t *q_pos = qbase + (size_t)wave * LIB_QCAP * (2 + CW);
+    uint32_t *q_gs = q_pos + LIB_QCAP;
+    uint32_t *q_cw = q_gs + LIB_QCAP;               // [CW][LIB_QCAP]
+
+    for (int i = threadIdx.x; i < pair_bytes / 16; i += LIB_BLOCK)
+        reinterpret_cast<u32x4 *>(pairs)[i] = reinterpret_cast<const u32x4 *>(a.pairs)[i];
+    for (int i = threadIdx.x; i < NG * 16; i += LIB_BLOCK) reinterpret_cast<u32x4 *>(pairs)[pair_bytes / 16 + i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < m * 4 * NMP; i += LIB_BLOCK) letters[i] = a.letters[i];
+    if (HAS_STRUCT)
+        for (int i = threadIdx.x; i < m * 7 * NMP; i += LIB_BLOCK) pssm[i] = a.pssm[i];
+    for (int i = threadIdx.x; i < NMP; i += LIB_BLOCK) {
+        thr_s[i] = a.thr_seq[i];
+        thr_t[i] = HAS_STRUCT ? a.thr_struct[i] : -INFINITY;
+    }
+    __syncthreads();                                // the only workgroup barrier: waves are independent from here on
+
+    const int64_t n_pos = a.n_pos;
+    const int shard = blockIdx.x & (a.hit_shards - 1);
+    unsigned long long *counter = a.hit_count + (size_t)shard * HIT_COUNTER_STRIDE;
+    const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.shard_cap;
+    const lds_cptr pairs_lds = lds_ptr_of(pairs);
+
+    // ---- phase B: the top cnt (<= 64) items [first, first + cnt) of this wave's queue, one per lane; items that
+    // still have flagged motifs left are written back from `first` on, `requeued` of them ----
+    int requeued = 0;
+    auto dense = [&](int first, int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool have = lane < cnt;
+        const int idx = first + (have ? lane : 0);
+        const uint32_t rel = q_pos[idx];
+        const uint32_t gsb = q_gs[idx];
+        uint32_t cw[CW];
+#pragma unroll
+        for (int k = 0; k < CW; ++k) cw[k] = q_cw[k * LIB_QCAP + idx];
+        uint32_t bits = have ? (gsb & 0x03030303u) : 0u;
+        const int g8 = (int)((gsb >> 2) & 63u) * 8;
+        const int64_t p = a.pos_base + (int64_t)rel;
+        const bool act = bits != 0;
+        const int q = act ? __builtin_ctz(bits) : 0;
+        bits &= bits - 1;
+        // ONE motif per lane and batch: an item with more flagged motifs goes back to the queue with the rest of its
+        // bits (a second round for the one or two such lanes of a batch would cost as much as a full batch)
+        const unsigned long long more = __builtin_amdgcn_ballot_w64(bits != 0);
+        if (more) {
+            if (bits != 0) {
+                const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
+                q_gs[slot] = (gsb & ~0x03030303u) | bits;
+#pragma unroll
+                for (int k = 0; k < CW; ++k) q_cw[k * LIB_QCAP + slot] = cw[k];
+            }
+            requeued = __popcll(more);
+        } else {
+            requeued = 0;
+        }
+        const int mo = g8 + (q >> 3) + 4 * (q & 1);   // pass-local motif
+        // exact sequence score: sequential fp64 sum (_pwm.c:36-64), float32 cast (:65)
+        double sc = 0.0;
+        const double *L = letters + mo;
+#pragma unroll
+        for (int j = 0; j < NP * 2; ++j) {
+            if (j < m) {
+                const uint32_t c = (cw[j >> 4] >> ((j & 15) * 2)) & 3u;
+                sc += L[(j * 4) * NMP + c * NMP];
+            }
+        }
+        const float f = (float)sc;
+        bool ok = act && ((double)f > thr_s[mo]);
+        double st = 0.0;
+        if (HAS_STRUCT) {
+            if (__builtin_amdgcn_ballot_w64(ok)) {
+                if (ok) {
+                    st = lib_struct_score<PROF_T, NMP>(a.profile, p, m, pssm, mo);
+                    ok = st > thr_t[mo];
+                }
+            }
+        }
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(ok);
+        if (hm) {
+            const int nh = __popcll(hm);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(counter, (unsigned long long)nh);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+            base = ((unsigned long long)hi << 32) | lo;
+            if (ok) {
+                const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                if ((int64_t)slot < a.shard_cap) {
+                    a.hit_pos[shard_off + slot] = p;
+                    a.hit_motif[shard_off + slot] = a.motif_base + mo;
+                    a.hit_seq[shard_off + slot] = f;
+                    if (HAS_STRUCT) a.hit_struct[shard_off + slot] = st;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- phase A: this workgroup's segments, this wave's 64-window chunks ----
+    int qn = 0;                                     // wave-uniform queue length (< 64 between chunks)
+    const int chunks_per_seg = (int)(a.seg_positions >> 6);
+    for (int64_t seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
+        const int64_t seg0 = seg * a.seg_positions;          // relative to pos_base
+        for (int c = wave; c < chunks_per_seg; c += LIB_WAVES) {
+            const int64_t rel0 = seg0 + (int64_t)c * 64;
+            if (rel0 >= a.span) break;                       // wave-uniform
+            const int64_t p0 = a.pos_base + rel0;            // multiple of 64
+            // the lane's letters: bytes [p0 + lane, p0 + lane + 2 NP) from NRAW aligned dwords
+            const int64_t al = p0 + (lane & ~3);
+            uint32_t raw[NRAW];
+            if (p0 + 64 + 4 * NRAW <= n_pos) {
+#pragma unroll
+                for (int k = 0; k < NRAW; ++k) raw[k] = *reinterpret_cast<const uint32_t *>(a.codes + al + 4 * k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NRAW; ++k) raw[k] = lib_codes4(a.codes, al + 4 * k, n_pos);
+            }
+            lds_cptr rowp[NP];
+            uint32_t cw[CW];
+            uint32_t badbits = 0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) cw[k] = 0;
+#pragma unroll
+            for (int k = 0; k < NP / 2; ++k) {
+                const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(lane & 3));
+                // letters 4k .. 4k+3 of the window; only the first m count
+                const int nb = m - 4 * k;
+                const uint32_t vm = nb >= 4 ? 0x04040404u : (nb > 0 ? (0x04040404u & ((1u << (8 * nb)) - 1u)) : 0u);
+                badbits |= w & vm;
+                const uint32_t x = w & 0x03030303u;
+                const uint32_t y = x | (x >> 6);             // pair (b0,b1) in bits 0-3, pair (b2,b3) in bits 16-19
+                rowp[2 * k] = pairs_lds + (2 * k) * (NG * 256) + ((y & 0xFu) << 4);
+                rowp[2 * k + 1] = pairs_lds + (2 * k + 1) * (NG * 256) + (((y >> 16) & 0xFu) << 4);
+                cw[k >> 2] |= ((y & 0xFu) | ((y >> 12) & 0xF0u)) << (8 * (k & 3));
+            }
+            // windows starting past the span belong to the next launch / do not exist; a window that cannot score (dead)
+            // takes its row 0 from the zero row: without the folded threshold bit 15 of its sums stays clear
+            const bool dead = (badbits != 0) || (rel0 + lane >= a.span);
+            if (!__ballot(!dead)) continue;                  // nothing scorable in this chunk (wave-uniform)
+            if (dead) rowp[0] = pairs_lds + pair_bytes;
+
+            const uint32_t relpos = (uint32_t)(rel0 + lane);
+            int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+            for (;;) {
+                while (qn >= 64) {                           // the top 64 items; the rest stays (LIFO)
+                    dense(qn - 64, 64);
+                    qn += requeued - 64;
+                }
+                if (g >= NG) break;
+                g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+            }
+        }
+    }
+    while (qn > 0) {                                    // the tail: at most 63 items + what they put back
+        dense(0, qn);
+        qn = requeued;
+    }
+}
+
+// LDS bytes of one pass (must match the carve-up in k_library)
+size_t lib_motif_bytes(int m, int npair, bool has_struct)
+{
+    return (size_t)(npair + 1) * 32 + (size_t)m * 32 + (has_struct ? (size_t)m * 56 : 0) + 16;     // +1: the zero row
+}
+
+size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * (2 + np_bucket / 8) * 4; }
+
+size_t lib_lds_bytes(int m, int npair, int nmp, bool has_struct, int np_bucket)
+{
+    return lib_motif_bytes(m, npair, has_struct) * (size_t)nmp + lib_queue_bytes(np_bucket);
+}
+
+int lib_np_bucket(int m) { return m <= 16 ? 8 : (m <= 32 ? 16 : 32); }
+
+// octet counts a pass may have (each is a kernel instantiation), largest first
+static const int LIB_NG_8[] = {16, 12, 8, 4, 2};
+static const int LIB_NG_16[] = {8, 4, 2};
+static const int LIB_NG_32[] = {4, 2};
+
+// the smallest supported octet count >= want_octets that is <= max_octets; when none is large enough, the largest
+// one within max_octets (the caller then needs more passes); 0 when even the smallest does not fit
+int lib_pick_ng(int np_bucket, int want_octets, int max_octets)
+{
+    const int *set = np_bucket == 8 ? LIB_NG_8 : (np_bucket == 16 ? LIB_NG_16 : LIB_NG_32);
+    const int n = np_bucket == 8 ? 5 : (np_bucket == 16 ? 3 : 2);
+    int best = 0;
+    for (int i = 0; i < n; ++i) {
+        if (set[i] > max_octets) continue;
+        if (best == 0 || set[i] >= want_octets) best = set[i];
+    }
+    return best;
+}
+
+template <int NG, int NP, typename PROF_T, bool HAS_STRUCT>
+static hipError_t launch_library_inst(const LibArgs &a, unsigned grid, size_t lds, hipStream_t stream)
+{
+    auto kern = k_library<NG, NP, PROF_T, HAS_STRUCT>;
+    static bool configured = false;                 // per instantiation; the attribute is sticky
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(lib_block(NP)), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int NG, int NP>
+static hipError_t launch_library_ng(const LibArgs &a, unsigned grid, size_t lds, hipStream_t stream)
+{
+    if (!a.pssm) return launch_library_inst<NG, NP, float, false>(a, grid, lds, stream);
+    if (a.profile_dtype == PFMSCAN_PROFILE_F64) return launch_library_inst<NG, NP, double, true>(a, grid, lds, stream);
+    return launch_library_inst<NG, NP, float, true>(a, grid, lds, stream);
+}
+
+hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream)
+{
+    if (a.span <= 0 || a.nmp <= 0) return hipSuccess;
+    const int np = lib_np_bucket(a.m);
+    const size_t lds = lib_lds_bytes(a.m, a.npair, a.nmp, a.pssm != nullptr, np);
+    if (lds > 160 * 1024 || a.ng * 8 != a.nmp || (a.seg_positions & 1023)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)std::min<int64_t>(a.n_seg, n_cu);
+#define LIB_CASE(NGV, NPV) \
+    if (np == NPV && a.ng == NGV) return launch_library_ng<NGV, NPV>(a, grid, lds, stream)
+    LIB_CASE(16, 8);
+    LIB_CASE(12, 8);
+    LIB_CASE(8, 8);
+    LIB_CASE(4, 8);
+    LIB_CASE(2, 8);
+    LIB_CASE(8, 16);
+    LIB_CASE(4, 16);
+    LIB_CASE(2, 16);
+    LIB_CASE(4, 32);
+    LIB_CASE(2, 32);
+#undef LIB_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pfmscan

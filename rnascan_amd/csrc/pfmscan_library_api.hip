@@ -1,0 +1,577 @@
+// pfmscan_library_api.hip -- C ABI of the multi-PFM library scan (include/pfmscan.h, "library" section): table
+// construction for k_library (pfmscan_library.hip), passes, hit packing / sorting.
+//
+// The prefilter of k_library may only DROP windows that cannot be hits.  For motif k with threshold thr and pair rows
+// e_t[idx] (t < npair; exact fp64 sums of two letter log-odds), with hi_t = max finite e_t:
+//     a window is a hit iff (double)(float)S64 > thr, S64 the sequential fp64 sum of its entries (_pwm.c:34-68);
+//     |S64 - S| and the float32 rounding stay below delta = 2^-23 * sum_t max|e_t| + 1e-9 (S = the real-number sum),
+//     so a hit has S > thr' = thr - delta, i.e. its DEFICIT sum_t (hi_t - e_t) < D = sum_t hi_t - thr'.
+// Deficits are quantised DOWN to v_t = floor(min(hi_t - e_t, D) / q), q = D / V, and stored as credits w_t = V - v_t
+// (unsigned 16 bit).  hit => sum_t v_t <= sum_t (hi_t - e_t)/q < V  =>  sum_t w_t >= X = (npair - 1) V + 1; an entry
+// with deficit >= D (-inf cells included) alone puts the sum at most at X - 1.  Pair row 0 also carries 32768 - X,
+// so "may be a hit" is bit 15 of the 16-bit sum.  V = 32767 / max(npair - 1, 1) keeps every sum below 65536 (two
+// motifs share a 32-bit word, a carry would corrupt the neighbour): 32768 - X + npair V = 32767 + V.
+// Integer adds are exact; the only slack is the rounding of the deficits (< npair * q in the score, one-sided).
+// A motif with +inf / NaN two-letter sums (background 0 for a letter the PFM uses) gets no prefilter: its row 0
+// is 32768 everywhere, every window goes to the exact pass.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pfmscan_ctx.hpp"
+
+using namespace pfmscan;
+
+namespace {
+
+struct LibPass {
+    int motif_base = 0, n_real = 0, nmp = 0, ng = 0;
+    size_t pairs_off = 0;      // uint16 elements into d_pairs
+    size_t letters_off = 0;    // doubles into d_letters
+    size_t pssm_off = 0;       // doubles into d_pssm
+    size_t thr_off = 0;        // doubles into d_thr: [nmp] seq thresholds, then [nmp] structure thresholds
+};
+
+// Credits of ONE motif at threshold thr (see the header comment): pairsum [npair][16], out [npair][16].
+// Returns the one-sided slack of the prefilter in score units (0 when no window can pass, inf without prefilter).
+double build_credits(const double *pairsum, int npair, double thr, uint16_t *out)
+{
+    std::fill(out, out + (size_t)npair * 16, (uint16_t)0);
+    if (thr == INFINITY) return 0.0;                      // nothing exceeds +inf: all credits 0, bit 15 never set
+    const int V = std::min(32767, 32767 / std::max(npair - 1, 1));
+    const int X = (npair - 1) * V + 1;
+    double sum_abs = 0.0, sum_hi = 0.0;
+    std::vector<double> HI((size_t)npair, 0.0);
+    bool special = false;
+    for (int t = 0; t < npair; ++t) {
+        double mx = 0.0, hi = -INFINITY;
+        for (int i = 0; i < 16; ++i) {
+            const double v = pairsum[t * 16 + i];
+            if (std::isfinite(v)) {
+                mx = std::max(mx, std::fabs(v));
+                hi = std::max(hi, v);
+            } else if (!(v == -INFINITY)) {
+                special = true;                           // +inf or NaN
+            }
+        }
+        HI[t] = std::isfinite(hi) ? hi : 0.0;
+        sum_abs += mx;
+        sum_hi += HI[t];
+    }
+    if (special) {                                        // every window goes to the exact pass
+        for (int i = 0; i < 16; ++i) out[i] = 32768u;
+        return INFINITY;
+    }
+    for (int i = 0; i < 16; ++i) out[i] = (uint16_t)(32768 - X);
+    const double delta = 0x1p-23 * sum_abs + 1e-9;
+    double D = sum_hi - (thr - delta);
+    D += 1e-12 * (std::fabs(D) + std::fabs(sum_hi) + std::fabs(thr)) + 1e-300;       // the fp64 evaluation of D itself
+    if (!(D > 0.0)) return 0.0;                           // no window can reach the threshold: credits stay 0
+    const double q = D / V;
+    for (int t = 0; t < npair; ++t)
+        for (int i = 0; i < 16; ++i) {
+            const double e = pairsum[t * 16 + i];
+            int w = 0;
+            if (e > -INFINITY) {
+                double deficit = HI[t] - e;
+                deficit -= 1e-12 * (std::fabs(HI[t]) + std::fabs(e));                 // rounded towards keeping the window
+                const double v = std::floor(std::max(deficit, 0.0) / q * (1.0 - 0x1p-40));
+                w = v >= (double)V ? 0 : V - (int)v;
+            }
+            out[t * 16 + i] = (uint16_t)(out[t * 16 + i] + w);
+        }
+    return q * npair;
+}
+
+// exact two-letter sums of one letter table [m][8] -> [npair][16], index c0 | c1 << 2 (an odd width's last pair
+// ignores its second letter)
+void pair_sums(const double *T, int m, double *out)
+{
+    const int npair = (m + 1) / 2;
+    for (int t = 0; t < npair; ++t)
+        for (int c0 = 0; c0 < 4; ++c0)
+            for (int c1 = 0; c1 < 4; ++c1)
+                out[t * 16 + (c0 | c1 << 2)] = T[(2 * t) * 8 + c0] + (2 * t + 1 < m ? T[(2 * t + 1) * 8 + c1] : 0.0);
+}
+
+}  // namespace
+
+struct pfmscan_library {
+    pfmscan_ctx *ctx = nullptr;
+    int n = 0, m = 0, npair = 0, np_bucket = 8;
+    bool has_struct = false;
+    std::vector<double> pairsum;       // [n][npair][16] exact two-letter sums, index c0 | c1 << 2
+    std::vector<LibPass> passes;
+    uint16_t *d_pairs = nullptr;
+    double *d_letters = nullptr, *d_pssm = nullptr, *d_thr = nullptr;
+    size_t pairs_elems = 0, thr_elems = 0;
+    std::vector<uint16_t> h_pairs;     // staging of the thresholded credit tables
+    std::vector<double> h_thr;
+    std::vector<double> cur_seq, cur_struct, eps;   // thresholds the device tables were built for
+    bool thr_valid = false;
+};
+
+static int lib_fail(pfmscan_ctx *ctx, int code, const std::string &msg) { return fail(ctx, code, msg); }
+
+extern "C" {
+
+int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const double *struct_pssms, int n_motifs, int m,
+                           pfmscan_library **out)
+{
+    if (!ctx || !out || !letter_tables) return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_create: NULL argument");
+    *out = nullptr;
+    if (n_motifs < 1 || n_motifs > 65535) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "library size outside 1..65535");
+    if (m < 1 || m > PFMSCAN_MAX_M)
+        return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "PFM width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    for (int64_t i = 0; i < (int64_t)n_motifs * m; ++i)
+        for (int c = 4; c < 8; ++c)
+            if (!std::isnan(letter_tables[i * 8 + c]))
+                return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "library scans need a 4-letter alphabet: columns 4..7 of every letter table must be NaN");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pfmscan_library *lib = new (std::nothrow) pfmscan_library();
+    if (!lib) return lib_fail(ctx, PFMSCAN_E_OOM, "out of host memory");
+    lib->ctx = ctx;
+    lib->n = n_motifs;
+    lib->m = m;
+    lib->npair = (m + 1) / 2;
+    lib->np_bucket = lib_np_bucket(m);
+    lib->has_struct = struct_pssms != nullptr;
+    const int npair = lib->npair;
+    lib->pairsum.resize((size_t)n_motifs * npair * 16);
+    for (int k = 0; k < n_motifs; ++k) pair_sums(letter_tables + (size_t)k * m * 8, m, lib->pairsum.data() + (size_t)k * npair * 16);
+    // passes: as many motif octets as the 160 KB of LDS hold next to the wave queues (the octet count of a pass is
+    // a template parameter of the kernel, so it comes from a small supported set); full passes first, the rest last
+    const size_t per_motif = lib_motif_bytes(m, npair, lib->has_struct);
+    const size_t fixed = lib_queue_bytes(lib->np_bucket);
+    const int fit_octets = (int)((160 * 1024 - fixed - 64) / per_motif / 8);
+    const int ng_max = lib_pick_ng(lib->np_bucket, 1 << 20, fit_octets);
+    if (ng_max < 1) {
+        delete lib;
+        return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "PFM too wide for the library kernel's LDS tables");
+    }
+    size_t pairs_elems = 0, letters_elems = 0, pssm_elems = 0, thr_elems = 0;
+    for (int base = 0; base < n_motifs;) {
+        LibPass ps;
+        ps.motif_base = base;
+        ps.n_real = std::min(n_motifs - base, ng_max * 8);
+        ps.ng = lib_pick_ng(lib->np_bucket, (ps.n_real + 7) / 8, ng_max);
+        ps.nmp = ps.ng * 8;
+        ps.pairs_off = pairs_elems;
+        ps.letters_off = letters_elems;
+        ps.pssm_off = pssm_elems;
+        ps.thr_off = thr_elems;
+        pairs_elems += (size_t)ps.ng * npair * 16 * 8;
+        letters_elems += (size_t)m * 4 * ps.nmp;
+        pssm_elems += (size_t)m * 7 * ps.nmp;
+        thr_elems += (size_t)2 * ps.nmp;
+        base += ps.n_real;
+        lib->passes.push_back(ps);
+    }
+    lib->pairs_elems = pairs_elems;
+    lib->thr_elems = thr_elems;
+    // transposed fp64 tables: [m * 4][nmp] letters, [m * 7][nmp] structure PSSM, per pass
+    std::vector<double> hl(letters_elems, 0.0), hp(lib->has_struct ? pssm_elems : 0, 0.0);
+    for (const LibPass &ps : lib->passes)
+        for (int l = 0; l < ps.n_real; ++l) {
+            const int k = ps.motif_base + l;
+            for (int j = 0; j < m; ++j) {
+                for (int c = 0; c < 4; ++c)
+                    hl[ps.letters_off + (size_t)(j * 4 + c) * ps.nmp + l] = letter_tables[((size_t)k * m + j) * 8 + c];
+                if (lib->has_struct)
+                    for (int c = 0; c < 7; ++c)
+                        hp[ps.pssm_off + (size_t)(j * 7 + c) * ps.nmp + l] = struct_pssms[((size_t)k * m + j) * 7 + c];
+            }
+        }
+    hipError_t e = hipMalloc((void **)&lib->d_pairs, pairs_elems * 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&lib->d_letters, letters_elems * 8);
+    if (e == hipSuccess) e = hipMemcpy(lib->d_letters, hl.data(), letters_elems * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && lib->has_struct) {
+        e = hipMalloc((void **)&lib->d_pssm, pssm_elems * 8);
+        if (e == hipSuccess) e = hipMemcpy(lib->d_pssm, hp.data(), pssm_elems * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&lib->d_thr, thr_elems * 8);
+    if (e != hipSuccess) {
+        pfmscan_library_destroy(lib);
+        return fail_hip(ctx, e, "uploading the library tables");
+    }
+    *out = lib;
+    return PFMSCAN_OK;
+}
+
+void pfmscan_library_destroy(pfmscan_library *lib)
+{
+    if (!lib) return;
+    if (lib->ctx) (void)hipSetDevice(lib->ctx->device);
+    if (lib->d_pairs) (void)hipFree(lib->d_pairs);
+    if (lib->d_letters) (void)hipFree(lib->d_letters);
+    if (lib->d_pssm) (void)hipFree(lib->d_pssm);
+    if (lib->d_thr) (void)hipFree(lib->d_thr);
+    delete lib;
+}
+
+int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack)
+{
+    if (!letter_table || !credits || m < 1 || m > PFMSCAN_MAX_M || std::isnan(thr_seq)) return PFMSCAN_E_BADARG;
+    const int npair = (m + 1) / 2;
+    std::vector<double> ps((size_t)npair * 16);
+    pair_sums(letter_table, m, ps.data());
+    const double s = build_credits(ps.data(), npair, thr_seq, credits);
+    if (slack) *slack = s;
+    return PFMSCAN_OK;
+}
+
+int pfmscan_library_info(const pfmscan_library *lib, int *n_motifs, int *m, int *n_passes, int *motifs_per_pass, double *max_eps)
+{
+    if (!lib) return PFMSCAN_E_BADARG;
+    if (n_motifs) *n_motifs = lib->n;
+    if (m) *m = lib->m;
+    if (n_passes) *n_passes = (int)lib->passes.size();
+    if (motifs_per_pass) *motifs_per_pass = lib->passes.empty() ? 0 : lib->passes[0].nmp;
+    if (max_eps) {
+        double mx = 0.0;
+        for (double v : lib->eps) mx = std::max(mx, v);
+        *max_eps = lib->thr_valid ? mx : NAN;
+    }
+    return PFMSCAN_OK;
+}
+
+}  // extern "C"
+
+// (re)build the thresholded credit tables when the thresholds changed; uploads on `st`
+static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const double *thr_seq, const double *thr_struct, hipStream_t st)
+{
+    const int n = lib->n, npair = lib->npair;
+    for (int k = 0; k < n; ++k) {
+        if (std::isnan(thr_seq[k]) || (lib->has_struct && std::isnan(thr_struct[k]))) return lib_fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
+        if (thr_seq[k] == -INFINITY)
+            return lib_fail(ctx, PFMSCAN_E_BADARG, "library hits need a finite sequence threshold (every window would be a hit; use the all-scores entry points)");
+    }
+    if (lib->thr_valid && std::equal(thr_seq, thr_seq + n, lib->cur_seq.begin()) &&
+        (!lib->has_struct || std::equal(thr_struct, thr_struct + n, lib->cur_struct.begin())))
+        return PFMSCAN_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(st));              // an earlier upload may still read the staging vectors
+    lib->thr_valid = false;
+    lib->h_pairs.assign(lib->pairs_elems, (uint16_t)0);
+    lib->h_thr.assign(lib->thr_elems, 0.0);
+    lib->eps.assign((size_t)n, 0.0);
+    std::vector<uint16_t> cr((size_t)npair * 16);
+    for (const LibPass &ps : lib->passes) {
+        for (int l = 0; l < ps.nmp; ++l) {
+            const int g = l / 8, slot = l % 8;
+            if (l >= ps.n_real) {                         // padding motif: all credits 0, never flagged
+                lib->h_thr[ps.thr_off + l] = INFINITY;
+                lib->h_thr[ps.thr_off + ps.nmp + l] = INFINITY;
+                continue;
+            }
+            const int k = ps.motif_base + l;
+            lib->h_thr[ps.thr_off + l] = thr_seq[k];
+            lib->h_thr[ps.thr_off + ps.nmp + l] = lib->has_struct ? thr_struct[k] : -INFINITY;
+            lib->eps[k] = build_credits(lib->pairsum.data() + (size_t)k * npair * 16, npair, thr_seq[k], cr.data());
+            for (int t = 0; t < npair; ++t)               // kernel layout [pair row][octet][entry][motif of the octet]
+                for (int i = 0; i < 16; ++i)
+                    lib->h_pairs[ps.pairs_off + (((size_t)t * ps.ng + g) * 16 + i) * 8 + slot] = cr[t * 16 + i];
+        }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(lib->d_pairs, lib->h_pairs.data(), lib->pairs_elems * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(lib->d_thr, lib->h_thr.data(), lib->thr_elems * 8, hipMemcpyHostToDevice, st));
+    lib->cur_seq.assign(thr_seq, thr_seq + n);
+    if (lib->has_struct) lib->cur_struct.assign(thr_struct, thr_struct + n);
+    lib->thr_valid = true;
+    return PFMSCAN_OK;
+}
+
+constexpr int64_t LIB_SEG = 16384;        // windows per work segment (segment s -> workgroup s mod grid, shard s mod 256)
+
+struct LibSink {
+    int64_t *pos;
+    int32_t *motif;
+    float *seq;
+    double *st;
+    unsigned long long *count;
+    int shards;
+    int64_t shard_cap;
+};
+
+// every pass of the library over [0, n_pos); asynchronous on `st`
+static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile, int profile_dtype,
+                   int64_t n_pos, const LibSink &sink, hipStream_t st)
+{
+    const int64_t max_span = (int64_t)1 << 31;
+    for (int64_t base = 0; base < n_pos; base += max_span) {
+        for (const LibPass &ps : lib->passes) {
+            LibArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.codes = d_codes;
+            a.profile = lib->has_struct ? d_profile : nullptr;
+            a.profile_dtype = profile_dtype;
+            a.n_pos = n_pos;
+            a.pos_base = base;
+            a.span = std::min<int64_t>(max_span, n_pos - base);
+            a.seg_positions = LIB_SEG;
+            a.n_seg = (a.span + a.seg_positions - 1) / a.seg_positions;
+            a.pairs = reinterpret_cast<const uint32_t *>(lib->d_pairs + ps.pairs_off);
+            a.letters = lib->d_letters + ps.letters_off;
+            a.pssm = lib->has_struct ? lib->d_pssm + ps.pssm_off : nullptr;
+            a.thr_seq = lib->d_thr + ps.thr_off;
+            a.thr_struct = lib->d_thr + ps.thr_off + ps.nmp;
+            a.m = lib->m;
+            a.npair = lib->npair;
+            a.nmp = ps.nmp;
+            a.ng = ps.ng;
+            a.motif_base = ps.motif_base;
+            a.shard_cap = sink.shard_cap;
+            a.hit_shards = sink.shards;
+            a.hit_pos = sink.pos;
+            a.hit_motif = sink.motif;
+            a.hit_seq = sink.seq;
+            a.hit_struct = sink.st;
+            a.hit_count = sink.count;
+            hipError_t e = launch_library(a, ctx->n_cu, st);
+            if (e != hipSuccess) return fail_hip(ctx, e, "launch k_library");
+        }
+    }
+    return PFMSCAN_OK;
+}
+
+static int lib_check(pfmscan_ctx *ctx, const pfmscan_library *lib, const uint8_t *codes, const void *profile, int profile_dtype,
+                     int64_t n_pos, const double *thr_seq, const double *thr_struct)
+{
+    if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
+    if (lib->ctx != ctx) return lib_fail(ctx, PFMSCAN_E_BADARG, "library belongs to another ctx");
+    if (n_pos < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
+    if (!thr_seq || (lib->has_struct && !thr_struct)) return lib_fail(ctx, PFMSCAN_E_BADARG, "threshold arrays are NULL");
+    if (n_pos > 0 && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (lib->has_struct) {
+        if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
+            return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs: profile_dtype must be F32 or F64");
+        if (n_pos > 0 && !profile) return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but profile is NULL");
+    }
+    return PFMSCAN_OK;
+}
+
+static int lib_scratch(pfmscan_ctx *ctx, int64_t capacity, int64_t n_pos, LibSink &sink)
+{
+    // shard s = workgroup & 255 gets every 256th 16k-window segment: the shards in use fill evenly, each has room for
+    // twice its share (short streams use few shards, small capacities let every shard take everything)
+    const int64_t active = std::max<int64_t>(1, std::min<int64_t>(LIB_SHARDS, (n_pos + LIB_SEG - 1) / LIB_SEG));
+    const int64_t shard_cap = std::max<int64_t>(std::min<int64_t>(capacity, capacity / active * 2 + 1024), 1);
+    const size_t slots = (size_t)shard_cap * LIB_SHARDS;
+    int rc;
+    if ((rc = ensure(ctx, ctx->lib_pos, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->lib_motif, slots * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->lib_seq, slots * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->lib_struct, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->lib_count, (size_t)(LIB_SHARDS + 2) * HIT_COUNTER_STRIDE * 8 + (LIB_SHARDS + 1) * 8))) return rc;
+    sink.pos = (int64_t *)ctx->lib_pos.p;
+    sink.motif = (int32_t *)ctx->lib_motif.p;
+    sink.seq = (float *)ctx->lib_seq.p;
+    sink.st = (double *)ctx->lib_struct.p;
+    sink.count = (unsigned long long *)ctx->lib_count.p;
+    sink.shards = LIB_SHARDS;
+    sink.shard_cap = shard_cap;
+    return PFMSCAN_OK;
+}
+
+// ---- sharded hits -> the caller's contiguous device arrays (order unspecified) ----
+namespace pfmscan {
+
+constexpr int PACK_BLOCK = 256;
+
+// starts[s] = exclusive prefix of min(count_s, shard_cap); *out_count = total hits (capacity + 1 at least when a shard
+// overflowed although the total fits, so that the caller sees "incomplete" exactly when something was dropped)
+__global__ __launch_bounds__(PACK_BLOCK) void k_lib_prefix(const unsigned long long *__restrict__ counts, int shards,
+                                                           int64_t shard_cap, int64_t capacity, int64_t *__restrict__ starts,
+                                                           unsigned long long *__restrict__ out_count)
+{
+    __shared__ int64_t held[LIB_SHARDS];
+    __shared__ unsigned long long total_s;
+    __shared__ int over_s;
+    if (threadIdx.x == 0) {
+        total_s = 0;
+        over_s = 0;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < shards; s += PACK_BLOCK) {
+        const unsigned long long n = counts[(size_t)s * HIT_COUNTER_STRIDE];
+        held[s] = (int64_t)n < shard_cap ? (int64_t)n : shard_cap;
+        atomicAdd(&total_s, n);
+        if ((int64_t)n > shard_cap) atomicOr(&over_s, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int s = 0; s < shards; ++s) {
+            starts[s] = run;
+            run += held[s];
+        }
+        starts[shards] = run;
+        unsigned long long t = total_s;
+        if (over_s && (int64_t)t <= capacity) t = (unsigned long long)capacity + 1;
+        *out_count = t;
+    }
+}
+
+__global__ __launch_bounds__(PACK_BLOCK) void k_lib_pack(const int64_t *__restrict__ starts, int shards, int64_t shard_cap,
+                                                         int64_t capacity, const int64_t *__restrict__ s_pos,
+                                                         const int32_t *__restrict__ s_motif, const float *__restrict__ s_seq,
+                                                         const double *__restrict__ s_st, int64_t *__restrict__ pos,
+                                                         int32_t *__restrict__ motif, float *__restrict__ seq, double *__restrict__ st)
+{
+    __shared__ int64_t start[LIB_SHARDS + 1];
+    for (int s = threadIdx.x; s <= shards; s += PACK_BLOCK) start[s] = starts[s];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * PACK_BLOCK + threadIdx.x;
+    if (i >= start[shards] || i >= capacity) return;
+    int lo = 0, hi = shards;                   // largest s with start[s] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t src = (int64_t)lo * shard_cap + (i - start[lo]);
+    pos[i] = s_pos[src];
+    if (motif) motif[i] = s_motif[src];
+    if (seq) seq[i] = s_seq[src];
+    if (st && s_st) st[i] = s_st[src];
+}
+
+}  // namespace pfmscan
+
+extern "C" {
+
+int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile,
+                             int profile_dtype, int64_t n_pos, const double *thr_seq, const double *thr_struct, int64_t capacity,
+                             int64_t *d_hit_pos, int32_t *d_hit_motif, float *d_hit_seq, double *d_hit_struct,
+                             uint64_t *d_hit_count, void *stream)
+{
+    int rc = lib_check(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (capacity < 0 || !d_hit_count || (capacity > 0 && (!d_hit_pos || !d_hit_motif)))
+        return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_hits_dev: bad hit buffers");
+    if (misaligned(d_codes) || misaligned(d_profile)) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "stream base pointers must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
+    LibSink sink;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink))) return rc;
+    const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
+    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
+    if ((rc = lib_run(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, sink, st))) return rc;
+    int64_t *starts = reinterpret_cast<int64_t *>(reinterpret_cast<unsigned char *>(sink.count) + (size_t)(LIB_SHARDS + 2) * HIT_COUNTER_STRIDE * 8);
+    hipLaunchKernelGGL(k_lib_prefix, dim3(1), dim3(PACK_BLOCK), 0, st, sink.count, LIB_SHARDS, sink.shard_cap, capacity, starts,
+                       reinterpret_cast<unsigned long long *>(d_hit_count));
+    HIP_TRY(ctx, hipGetLastError());
+    if (capacity > 0) {
+        const int64_t most = std::min<int64_t>(capacity, sink.shard_cap * LIB_SHARDS);
+        hipLaunchKernelGGL(k_lib_pack, dim3((unsigned)((most + PACK_BLOCK - 1) / PACK_BLOCK)), dim3(PACK_BLOCK), 0, st, starts,
+                           LIB_SHARDS, sink.shard_cap, capacity, sink.pos, sink.motif, sink.seq, lib->has_struct ? sink.st : nullptr,
+                           d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return PFMSCAN_OK;
+}
+
+int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const double *thr_seq, const double *thr_struct,
+                                int64_t capacity, int64_t *hit_pos, int32_t *hit_motif, float *hit_seq, double *hit_struct,
+                                int64_t *n_hits)
+{
+    if (!n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
+    if (ctx->staged_n < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "no stream staged (call pfmscan_stage first)");
+    if (!ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
+    if (lib->has_struct && !ctx->staged_profile && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but no profile is staged");
+    const int64_t n_pos = ctx->staged_n;
+    int rc = lib_check(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (capacity > 0 && (!hit_pos || !hit_motif)) return lib_fail(ctx, PFMSCAN_E_BADARG, "hit_pos / hit_motif is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
+    LibSink sink;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink))) return rc;
+    const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
+    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
+    if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, sink, st))) return rc;
+    std::vector<unsigned long long> counters((size_t)LIB_SHARDS * HIT_COUNTER_STRIDE);
+    HIP_TRY(ctx, hipMemcpyAsync(counters.data(), sink.count, counter_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint64_t total = 0, worst = 0;
+    for (int s = 0; s < LIB_SHARDS; ++s) {
+        total += counters[(size_t)s * HIT_COUNTER_STRIDE];
+        worst = std::max<uint64_t>(worst, counters[(size_t)s * HIT_COUNTER_STRIDE]);
+    }
+    *n_hits = (int64_t)total;
+    if ((int64_t)total > capacity || (int64_t)worst > sink.shard_cap) {
+        *n_hits = (int64_t)std::max<uint64_t>(total, worst * LIB_SHARDS);       // enough that every shard fits next time
+        return lib_fail(ctx, PFMSCAN_E_CAPACITY, "hit buffer too small: " + std::to_string(total) + " hits, capacity " + std::to_string(capacity));
+    }
+    if (total == 0) return PFMSCAN_OK;
+    // shards -> one run ordered by (position, motif) on the device (pfmscan_sort.hip)
+    int key_bits = 1, motif_bits = 1;
+    while (key_bits < 62 && ((int64_t)1 << key_bits) < n_pos) ++key_bits;
+    while (motif_bits < 16 && (1 << motif_bits) < lib->n) ++motif_bits;
+    if (key_bits + motif_bits > 63) return lib_fail(ctx, PFMSCAN_E_BADARG, "stream too long for the (position, motif) sort key");
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, sort_temp_bytes((int64_t)total, key_bits + motif_bits, &temp_bytes));
+    if ((rc = ensure(ctx, ctx->sort_keys_in, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_keys_out, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals_in, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals_out, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_temp, std::max<size_t>(temp_bytes, 256)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_seq, total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_struct, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_motif, total * 4))) return rc;
+    GatherArgs g;
+    g.hit_pos = sink.pos;
+    g.hit_seq = sink.seq;
+    g.hit_struct = lib->has_struct ? sink.st : nullptr;
+    g.counts = sink.count;
+    g.shards = LIB_SHARDS;
+    g.shard_cap = sink.shard_cap;
+    g.total = (int64_t)total;
+    g.key_bits = key_bits;
+    g.keys_in = (int64_t *)ctx->sort_keys_in.p;
+    g.keys_out = (int64_t *)ctx->sort_keys_out.p;
+    g.vals_in = (int64_t *)ctx->sort_vals_in.p;
+    g.vals_out = (int64_t *)ctx->sort_vals_out.p;
+    g.temp = ctx->sort_temp.p;
+    g.temp_bytes = ctx->sort_temp.cap;
+    g.seq_out = (float *)ctx->sort_seq.p;
+    g.struct_out = (double *)ctx->sort_struct.p;
+    g.hit_motif = sink.motif;
+    g.motif_out = (int32_t *)ctx->sort_motif.p;
+    g.motif_bits = motif_bits;
+    {
+        hipError_t e = launch_gather_sorted(g, st);
+        if (e != hipSuccess) return fail_hip(ctx, e, "gather + sort of the library hits");
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(hit_pos, g.keys_out, total * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(hit_motif, g.motif_out, total * 4, hipMemcpyDeviceToHost, st));
+    if (hit_seq) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, st));
+    if (hit_struct && lib->has_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hit_struct && !lib->has_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
+    return PFMSCAN_OK;
+}
+
+int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *codes, const void *profile,
+                              int profile_dtype, int64_t n_pos, const double *thr_seq, const double *thr_struct, int64_t capacity,
+                              int64_t *hit_pos, int32_t *hit_motif, float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    if (!ctx || !lib || !n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (n_pos < 0 || capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (!codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (lib->has_struct && !profile) return lib_fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
+    int rc = pfmscan_stage(ctx, codes, lib->has_struct ? profile : nullptr, profile_dtype, n_pos);
+    if (rc) return rc;
+    return pfmscan_library_hits_staged(ctx, lib, thr_seq, thr_struct, capacity, hit_pos, hit_motif, hit_seq, hit_struct, n_hits);
+}
+
+}  // extern "C"

@@ -1,6 +1,6 @@
 // pfmscan_sort.hip -- hits of the ctx-owned sharded buffers -> position order, on the device.
 //
-// The hits kernels append in arrival order to 32 shards.  The host API returns them sorted by position
+// The hits kernels append in arrival order to 32 shards (256 for library scans, which sort by (position, motif)).  The host API returns them sorted by position
 // (rnascan's tables are in window order, rnascan.py:263-275).  Gathering the shards with one small copy each
 // and sorting an index vector on the host cost 22 ms per motif for 760 k hits -- 100x the scan itself.  Here
 // the shards are packed into one key/value run (key = stream position, value = source slot), sorted with
@@ -16,18 +16,19 @@
 namespace pfmscan {
 
 constexpr int SORT_BLOCK = 256;
-constexpr int SORT_MAX_SHARDS = 64;
+constexpr int SORT_MAX_SHARDS = 256;
 
 // element i of the packed run <- shard s, entry j (shards in order, min(count, cap) entries each)
 __global__ __launch_bounds__(SORT_BLOCK) void k_pack_shards(const int64_t *__restrict__ hit_pos,
                                                             const unsigned long long *__restrict__ counts, int shards,
                                                             int64_t shard_cap, int64_t total,
-                                                            int64_t *__restrict__ keys, int64_t *__restrict__ vals)
+                                                            int64_t *__restrict__ keys, int64_t *__restrict__ vals,
+                                                            const int32_t *__restrict__ hit_motif, int motif_bits)
 {
     __shared__ int64_t start[SORT_MAX_SHARDS + 1];
-    if ((int)threadIdx.x < shards) {
-        int64_t n = (int64_t)counts[threadIdx.x * HIT_COUNTER_STRIDE];
-        start[threadIdx.x + 1] = n < shard_cap ? n : shard_cap;
+    for (int t = threadIdx.x; t < shards; t += SORT_BLOCK) {
+        int64_t n = (int64_t)counts[t * HIT_COUNTER_STRIDE];
+        start[t + 1] = n < shard_cap ? n : shard_cap;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -43,8 +44,20 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_pack_shards(const int64_t *__res
         if (start[mid] <= i) lo = mid; else hi = mid;
     }
     const int64_t src = (int64_t)lo * shard_cap + (i - start[lo]);
-    keys[i] = hit_pos[src];
+    // library scans sort by (position, motif): the motif index rides in the low bits of the key
+    keys[i] = hit_motif ? ((hit_pos[src] << motif_bits) | (int64_t)hit_motif[src]) : hit_pos[src];
     vals[i] = src;
+}
+
+// composite keys of a sorted library run -> positions (in place) and motif indices
+__global__ __launch_bounds__(SORT_BLOCK) void k_split_keys(int64_t *__restrict__ keys, int64_t total, int motif_bits,
+                                                           int32_t *__restrict__ motif_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x;
+    if (i >= total) return;
+    const int64_t k = keys[i];
+    motif_out[i] = (int32_t)(k & (((int64_t)1 << motif_bits) - 1));
+    keys[i] = k >> motif_bits;
 }
 
 __global__ __launch_bounds__(SORT_BLOCK) void k_gather_scores(const int64_t *__restrict__ order, int64_t total,
@@ -72,13 +85,18 @@ hipError_t launch_gather_sorted(const GatherArgs &g, hipStream_t stream)
     if (g.shards > SORT_MAX_SHARDS) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((g.total + SORT_BLOCK - 1) / SORT_BLOCK);
     hipLaunchKernelGGL(k_pack_shards, dim3(grid), dim3(SORT_BLOCK), 0, stream, g.hit_pos, g.counts, g.shards, g.shard_cap,
-                       g.total, g.keys_in, g.vals_in);
+                       g.total, g.keys_in, g.vals_in, g.hit_motif, g.motif_bits);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t bytes = g.temp_bytes;
     e = rocprim::radix_sort_pairs(g.temp, bytes, g.keys_in, g.keys_out, g.vals_in, g.vals_out, (size_t)g.total, 0u,
-                                  (unsigned)g.key_bits, stream);
+                                  (unsigned)(g.key_bits + (g.hit_motif ? g.motif_bits : 0)), stream);
     if (e != hipSuccess) return e;
+    if (g.hit_motif) {
+        hipLaunchKernelGGL(k_split_keys, dim3(grid), dim3(SORT_BLOCK), 0, stream, g.keys_out, g.total, g.motif_bits, g.motif_out);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (g.hit_seq || g.hit_struct) {
         hipLaunchKernelGGL(k_gather_scores, dim3(grid), dim3(SORT_BLOCK), 0, stream, g.vals_out, g.total, g.hit_seq,
                            g.hit_struct, g.seq_out, g.struct_out);

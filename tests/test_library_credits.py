@@ -1,0 +1,91 @@
+"""The integer prefilter of the multi-PFM library kernel (pfmscan_library_api.hip, build_credits) must never drop a
+hit.  No GPU needed: the credit table of one motif is built by the host code of libpfmscan and checked here
+EXHAUSTIVELY -- every window of 4^m letter combinations -- against the reference's scoring rule
+(_pwm.c:34-68: sequential fp64 sum, float32 cast; rnascan.py:263: strict `>`)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from rnascan_amd import _lib
+
+
+def all_windows(n_letters):
+    return np.array(list(itertools.product(range(4), repeat=n_letters)), dtype=np.int64)
+
+
+def exact_scores(T, codes):
+    s = np.zeros(codes.shape[0], dtype=np.float64)
+    for j in range(T.shape[0]):                       # sequential fp64 sum, as _pwm.c:36-64
+        with np.errstate(invalid="ignore"):
+            s = s + T[j, codes[:, j]]
+    return s.astype(np.float32)
+
+
+def credit_sums(credits, codes, m):
+    npair = (m + 1) // 2
+    tot = np.zeros(codes.shape[0], dtype=np.int64)
+    for t in range(npair):
+        idx = codes[:, 2 * t] | (codes[:, 2 * t + 1] << 2)
+        tot += credits[t, idx].astype(np.int64)
+    return tot
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("inf_frac", [0.0, 0.2])
+def test_prefilter_never_drops_a_hit(m, inf_frac):
+    rng = np.random.default_rng(31 * m + int(10 * inf_frac))
+    n_letters = m + (m & 1)                            # an odd width's last pair also sees the letter AFTER the window
+    codes = all_windows(n_letters)
+    for trial in range(6):
+        T = np.full((m, 8), np.nan)
+        T[:, :4] = rng.normal(0, 2.5, size=(m, 4)) * rng.choice([1.0, 1.0, 30.0])
+        if inf_frac:
+            T[:, :4][rng.random((m, 4)) < inf_frac] = -np.inf
+        f = exact_scores(T, codes)
+        fin = np.sort(f[np.isfinite(f)].astype(np.float64))
+        thrs = [6.0, 0.0, -3.5, 1e4, -1e4, np.inf]
+        if fin.size:
+            thrs += [float(fin[int(q * (fin.size - 1))]) for q in (0.0, 0.5, 0.9, 0.99, 1.0)]            # ON scores
+            thrs += [float(np.nextafter(np.float32(fin[int(0.9 * (fin.size - 1))]), np.float32(-np.inf)))]
+        for thr in thrs:
+            credits, slack = _lib.credit_table(T, thr)
+            tot = credit_sums(credits, codes, m)
+            assert tot.max() <= 65535, "a 16-bit sum would carry into the neighbouring motif"
+            flagged = (tot & 0x8000) != 0
+            hit = f.astype(np.float64) > thr
+            assert not (hit & ~flagged).any(), "prefilter dropped a hit (m=%d thr=%r)" % (m, thr)
+            if np.isfinite(slack) and flagged.any():
+                # and it is tight: every kept window scores within `slack` (+ the float32 rounding) of the threshold
+                kept = f[flagged].astype(np.float64)
+                assert (kept > thr - slack - 1e-5 * (1 + abs(thr)) - 2e-6 * np.abs(T[:, :4][np.isfinite(T[:, :4])]).sum()).all()
+
+
+def test_prefilter_disabled_for_plus_inf_cells():
+    T = np.full((4, 8), np.nan)
+    T[:, :4] = np.random.default_rng(1).normal(0, 2, size=(4, 4))
+    T[1, 2] = np.inf                                   # background 0 for a letter the PFM uses
+    credits, slack = _lib.credit_table(T, 3.0)
+    assert np.isinf(slack)
+    codes = all_windows(4)
+    assert ((credit_sums(credits, codes, 4) & 0x8000) != 0).all()          # everything goes to the exact pass
+
+
+def test_wide_motifs_keep_sums_inside_16_bits():
+    rng = np.random.default_rng(9)
+    for m in (12, 18, 33, 64):
+        T = np.full((m, 8), np.nan)
+        T[:, :4] = rng.normal(0, 3, size=(m, 4))
+        for thr in (6.0, -50.0, 40.0):
+            credits, slack = _lib.credit_table(T, thr)
+            assert int(credits.max(axis=1).astype(np.int64).sum()) <= 65535
+            # random windows: hits are never dropped
+            codes = rng.integers(0, 4, size=(200000, m + (m & 1)))
+            f = exact_scores(T, codes)
+            flagged = (credit_sums(credits, codes, m) & 0x8000) != 0
+            assert not ((f.astype(np.float64) > thr) & ~flagged).any()
+            # best window of the motif: certainly kept when it is a hit
+            best = np.argmax(T[:, :4], axis=1)[None, :]
+            best = np.concatenate([best, np.zeros((1, m & 1), dtype=best.dtype)], axis=1)
+            if float(exact_scores(T, best)[0]) > thr:
+                assert (credit_sums(credits, best, m) & 0x8000).all()
