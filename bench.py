@@ -12,8 +12,10 @@ path over the whole batch, inputs already resident in HBM.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: records are independent, so every rank scans its own
-100k-record shard (weak scaling), no data-path collective; only the timing
-barrier and a MAX over ranks use RCCL.
+shard (weak scaling), no data-path collective; only the timing barrier and a MAX
+over ranks use RCCL.  With 8 ranks the default shard is 125k records: BASELINE
+configs[3] ("C4": 1M records x 3 kb over 8 GPUs); the line then carries every rank's
+kernel time and a per-rank parity sample against the CPU oracle.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is computed from the ALGORITHMIC
 bytes (29 B read per position + 12 B written per window)
@@ -94,7 +96,8 @@ def main():
     ap.add_argument("--settle", type=int, default=15,
                     help="untimed launches right after data generation, BEFORE the --warmup steps: the chip's clocks "
                          "take ~10 launches to settle after the generation kernels (per-dispatch times ramp 3.1 -> 2.3 ms)")
-    ap.add_argument("--records", type=int, default=100000, help="records per GPU")
+    ap.add_argument("--records", type=int, default=None,
+                    help="records per GPU [100000; 125000 with 8 GPUs = C4: 1M records over the node]")
     ap.add_argument("--length", type=int, default=3000)
     ap.add_argument("--width", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
@@ -103,20 +106,29 @@ def main():
                     help="skip the reference-structured Python baseline (B-ref of BASELINE.md section 3)")
     ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
                     help="c3: seq+struct w=12 (the headline metric); c2: sequence-only PFM (BASELINE configs[1], use --width 8); "
-                         "c5: a library of --motifs seq+struct PFM pairs over the same resident records, hits mode "
-                         "(BASELINE configs[4]); value is then window x motif pairs per second")
+                         "c5: a library of --motifs seq+struct PFM pairs over the same resident records, every motif in ONE "
+                         "pass of the library kernel, thresholded hits (BASELINE configs[4]); value is then window x motif "
+                         "pairs per second")
     ap.add_argument("--motifs", type=int, default=256, help="PFM pairs of --workload c5")
     ap.add_argument("--variant", choices=["finite", "inf"], default="finite",
                     help="finite: pseudocount 0.01 PSSMs (headline); inf: pseudocount 0 PSSMs with -inf cells, profile with "
                          "exact zeros and 0.1 %% foreign letters (exercises nan_to_num / NaN windows at full size)")
-    ap.add_argument("--mode", choices=["scores", "hits", "hits2"], default="scores",
+    ap.add_argument("--mode", choices=["scores", "hits", "hits2", "library"], default="scores",
                     help="scores: all-scores (the headline, 41.1 B/window); hits: thresholded hits, one fused pass "
                          "(29.1 B/window + 20 B/hit); hits2: candidate-then-verify (letters pass, structure only at its hits)")
     ap.add_argument("--profile-dtype", choices=["float32", "float64"], default="float32",
                     help="device storage of the profile rows (float32 = the headline, 41.1 B/window; float64 = the strict "
                          "variant of SURVEY 8d, 69.2 B/window)")
-    ap.add_argument("--minscore", type=float, default=6.0, help="threshold of --mode hits (seq > m and struct > m)")
+    ap.add_argument("--minscore", type=float, default=None,
+                    help="one threshold for both sides (the reference's -m): seq > m and struct > m; overrides the two below")
+    ap.add_argument("--minscore-seq", type=float, default=6.0, help="sequence threshold of the hits modes [the CLI's default -m 6]")
+    ap.add_argument("--minscore-struct", type=float, default=None,
+                    help="structure threshold of the hits modes [auto: the quantile of the structure scores of the windows "
+                         "passing the sequence threshold that gives a combined hit rate of --hit-rate]")
+    ap.add_argument("--hit-rate", type=float, default=1e-4, help="target combined hit rate of the auto structure threshold (SURVEY 8d C5)")
     args = ap.parse_args()
+    if args.minscore is not None:
+        args.minscore_seq = args.minscore_struct = args.minscore
 
     import torch
     from rnascan_amd import _lib
@@ -124,6 +136,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.records is None:
+        args.records = 125000 if world == 8 else 100000
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libpfmscan has no CPU fallback)")
     # rehearsal on a one-GPU box: PFMSCAN_BENCH_REHEARSE=1 puts every rank on device 0 and rendezvous over gloo
@@ -144,13 +158,14 @@ def main():
     ctx = _lib.Context(local_rank)
     table, spssm = make_pssms(args.width, args.variant)
     seq_only = args.workload == "c2"
+    is_lib = args.workload == "c5"
     motif = ctx.motif(table, None if seq_only else spssm)
-    library = []
-    if args.workload == "c5":
-        args.mode = "hits2"
-        for k in range(args.motifs):                      # seeds 1000 + k
-            t_k, s_k = make_pssms(args.width, args.variant, seed=1000 + k)
-            library.append(ctx.motif(t_k, s_k))
+    library = None
+    if is_lib:
+        args.mode = "library"
+        tabs = [make_pssms(args.width, args.variant, seed=1000 + k) for k in range(args.motifs)]      # seeds 1000 + k
+        lib_T, lib_P = np.stack([t for t, _ in tabs]), np.stack([p for _, p in tabs])
+        library = ctx.library(lib_T, lib_P)
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank,
                                         foreign=0.001 if args.variant == "inf" else 0.0,
                                         zero_snap=args.variant == "inf")
@@ -171,27 +186,57 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
-    cap = 1 << 24
-    if args.mode in ("hits", "hits2"):
+    # ---- thresholds of the hits modes: the CLI's default -m 6 on the sequence side; the structure threshold, unless
+    # given, is the quantile that makes the COMBINED hit rate --hit-rate ("threshold chosen for ~1e-4"), so
+    # that hit emission, the sharded counters and (library) the structure verification all carry real load
+    thr_seq, thr_struct, thr_note = args.minscore_seq, args.minscore_struct, "given"
+    if args.mode != "scores" and not seq_only and thr_struct is None:
+        # pooled over up to 8 motifs of the library (their score distributions differ), or the one motif
+        probe = [tabs[k] for k in range(0, len(tabs), max(1, len(tabs) // 8))][:8] if is_lib else [None]
+        pooled, n_pass = [], 0
+        for tp in probe:
+            m0 = ctx.motif(*tp) if is_lib else motif
+            ctx.scan_dev(m0, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, out_seq.data_ptr(), out_st.data_ptr(), stream)
+            torch.cuda.synchronize()
+            sel = out_st[out_seq.double() > thr_seq]
+            pooled.append(sel[torch.isfinite(sel)].clone())
+            if is_lib:
+                m0.close()
+        sel = torch.cat(pooled)
+        rate_seq = float(sel.numel()) / (windows * len(probe))
+        keep = min(1.0, args.hit_rate / max(rate_seq, 1e-30))
+        if sel.numel() == 0:
+            thr_struct = -1e30
+        else:
+            srt, _ = torch.sort(sel)
+            thr_struct = float(srt[min(sel.numel() - 1, int((1.0 - keep) * sel.numel()))])
+        thr_note = ("auto: quantile of the structure scores of the %.3g of windows with seq > %g (pooled over %d motif%s), for a "
+                    "combined rate of %g" % (rate_seq, thr_seq, len(probe), "s" if len(probe) > 1 else "", args.hit_rate))
+        del sel, pooled
+        out_seq.zero_()
+        out_st.zero_()
+    if seq_only or thr_struct is None:
+        thr_struct = -np.inf if seq_only else thr_struct
+
+    cap = 1 << 25 if is_lib else 1 << 24
+    if args.mode != "scores":
         hit_pos = torch.empty(cap, dtype=torch.int64, device=dev)
+        hit_motif = torch.empty(cap if is_lib else 1, dtype=torch.int32, device=dev)
         hit_seq = torch.empty(cap, dtype=torch.float32, device=dev)
         hit_st = torch.empty(cap, dtype=torch.float64, device=dev)
         hit_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
-        if library:
-            for mo in library:
-                hit_count.zero_()
-                ctx.hits_adaptive_dev(mo, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, args.minscore,
-                                      args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
-                                      hit_count.data_ptr(), stream)
-            return
-        if args.mode in ("hits", "hits2"):
+        if is_lib:
+            ctx.library_hits_dev(library, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, thr_seq, thr_struct, cap,
+                                 hit_pos.data_ptr(), hit_motif.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
+                                 hit_count.data_ptr(), stream)
+        elif args.mode in ("hits", "hits2"):
             hit_count.zero_()
-            (ctx.hits_dev if args.mode == "hits" else ctx.hits_adaptive_dev)(motif, codes.data_ptr(), None if seq_only else profile.data_ptr(),
-                         _lib.PROFILE_NONE if seq_only else ptype, n_pos, args.minscore,
-                         args.minscore, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
-                         hit_count.data_ptr(), stream)
+            (ctx.hits_dev if args.mode == "hits" else ctx.hits_adaptive_dev)(
+                motif, codes.data_ptr(), None if seq_only else profile.data_ptr(), _lib.PROFILE_NONE if seq_only else ptype,
+                n_pos, thr_seq, thr_struct, cap, hit_pos.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
+                hit_count.data_ptr(), stream)
         elif seq_only:
             ctx.scan_dev(motif, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, out_seq.data_ptr(), None, stream)
         else:
@@ -206,60 +251,101 @@ def main():
     # them (15 launches of the 0.3 ms sequence-only kernel are over before the ramp is: C2 read 0.33 ms with
     # them and 0.29 ms in steady state)
     settled = 0
-    if not library:
-        t_s = time.perf_counter()
-        while settled < args.settle or (time.perf_counter() - t_s < 0.040 and settled < 5000):
-            step()
-            settled += 1
-            if settled >= args.settle and settled % 16 == 0:
-                torch.cuda.synchronize()
-        torch.cuda.synchronize()
+    t_s = time.perf_counter()
+    while settled < (2 if is_lib else args.settle) or (time.perf_counter() - t_s < 0.040 and settled < 5000):
+        step()
+        settled += 1
+        if settled >= args.settle and settled % 16 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # one HIP event per step boundary, on the launch stream: the per-step durations give median / min / max over
+    # exactly the timed dispatches (directly comparable with a rocprofv3 kernel trace of the same steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
-    e1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / args.steps          # HIP events on the launch stream
+    step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+    kernel_ms = float(evs[0].elapsed_time(evs[args.steps]) / args.steps)          # HIP events on the launch stream
+    kernel_ms_rank = kernel_ms
+    n_hits = None
+    if args.mode != "scores":
+        n_hits = int(hit_count.item())
+
+    # ---- per-rank parity sample (multi-GPU runs): a few records of THIS rank's shard against the CPU oracle
+    rank_parity = None
+    if world > 1 and args.mode == "scores" and not seq_only and not args.no_cpu_baseline:
+        from oracle import oracle
+        oracle.build()
+        stride = args.length + 1
+        nrec = min(args.records, 8)
+        c = codes[: nrec * stride].cpu().numpy()
+        pr = profile[: nrec * stride].cpu().numpy()
+        ref_seq, ref_st = oracle.stream_seq(c, table), oracle.stream_struct(pr, spssm)
+        got_seq, got_st = out_seq[: nrec * stride].cpu().numpy(), out_st[: nrec * stride].cpu().numpy()
+        v = ~np.isnan(ref_seq)
+        ok_seq = bool(np.array_equal(np.isnan(got_seq), ~v) and np.array_equal(got_seq[v].view(np.uint32), ref_seq[v].view(np.uint32)))
+        vs = np.isfinite(ref_st) & (np.abs(ref_st) < 1e9)
+        rank_parity = bool(ok_seq and float(np.abs(got_st[vs] - ref_st[vs]).max()) <= 1e-6)
+
+    rank_ms, rank_ok, rank_hits = [kernel_ms], [rank_parity], [n_hits]
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
+        box = [None] * world
+        dist.all_gather_object(box, (kernel_ms_rank, rank_parity, n_hits))
+        rank_ms, rank_ok, rank_hits = [b[0] for b in box], [b[1] for b in box], [b[2] for b in box]
 
     result = None
     if rank == 0:
-        total_windows = windows * world * args.steps * (len(library) if library else 1)
+        n_motifs = args.motifs if is_lib else 1
+        total_windows = windows * world * args.steps * n_motifs
         in_b, out_b, hit_b = (1, 4, 12) if seq_only else (29 if ptype == _lib.PROFILE_F32 else 57, 12, 20)
         alg_bytes = args.records * args.length * in_b + windows * out_b      # per launch, per GPU
-        n_hits = None
         if args.mode != "scores":
-            n_hits = int(hit_count.item())
             alg_bytes = args.records * args.length * in_b + min(n_hits, cap) * hit_b
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile) and args.mode == "scores" and args.profile_dtype == "float32":
             try:
-                for tj in json.load(open(tfile)).get("entries", []):
+                tj_all = json.load(open(tfile))
+                for tj in tj_all.get("entries", []):
                     if (tj.get("workload") == args.workload and tj.get("records") == args.records
                             and tj.get("length") == args.length and tj.get("width") == args.width):
                         traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_source = "profiles/pmc_traffic.json (%s; rocprofv3 --pmc passes of %s, not measured in this run)" % (
+                            tj.get("kernel", "?"), tj.get("date", tj_all.get("date", "?")))
             except Exception:
                 traffic = None
+        shard = "C4: 1M" if (world == 8 and args.records == 125000) else "%d x %d" % (world, args.records)
+        if is_lib:
+            wl = ("C5: library of %d seq+struct PFM pairs (width %d) x %d synthetic records x %d nt per GPU, resident stream, "
+                  "every motif in one pass (k_library: integer two-letter prefilter in LDS, exact re-score + structure "
+                  "verification of the survivors), thresholded hits per motif" % (n_motifs, args.width, args.records, args.length))
+        elif seq_only:
+            wl = "C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes" % (args.records, args.length, args.width)
+        else:
+            wl = ("%s: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, uint8 codes + %s "
+                  "[n][7] profile, %s" % ("C4 (1M records x 3 kb over 8 GPUs)" if shard.startswith("C4") else "C3", args.records,
+                                          args.length, args.width, args.profile_dtype,
+                                          "all-scores (f32 seq + f64 struct per window)" if args.mode == "scores" else "thresholded hits"))
         result = {
-            "metric": ("scored window x motif pairs/sec (%d-PFM library, seq+struct, w=%d)" % (len(library), args.width)) if library
+            "metric": ("scored window x motif pairs/sec (%d-PFM library, seq+struct, w=%d)" % (n_motifs, args.width)) if is_lib
                       else "scored windows/sec (%s, w=%d)" % ("seq-only" if seq_only else "seq+struct", args.width),
             "value": total_windows / elapsed,
-            "unit": "window-motif pairs/s" if library else "windows/s",
+            "unit": "window-motif pairs/s" if is_lib else "windows/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -270,31 +356,54 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("C5: library of %d seq+struct PFM pairs (width %d) x %d synthetic records x %d nt per GPU, "
-                             "resident stream, thresholded hits per motif (candidate-then-verify)"
-                             % (len(library), args.width, args.records, args.length)) if library else
-                            ("C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes"
-                             % (args.records, args.length, args.width)) if seq_only else
-                            ("C3: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, "
-                             "uint8 codes + %s [n][7] profile, all-scores (f32 seq + f64 struct per window)"
-                             % (args.records, args.length, args.width, args.profile_dtype)),
+                "workload": wl,
                 "records_per_gpu": args.records, "record_length": args.length, "pfm_width": args.width,
-                "variant": args.variant, "settle_launches": settled, "windows_per_gpu_per_step": windows, "mode": "all-scores" if args.mode == "scores" else "hits",
-                "minscore": None if args.mode == "scores" else args.minscore, "hits_per_step": n_hits,
+                "variant": args.variant, "settle_launches": settled, "windows_per_gpu_per_step": windows,
+                "mode": {"scores": "all-scores", "library": "library hits"}.get(args.mode, "hits"),
+                "minscore_seq": None if args.mode == "scores" else thr_seq,
+                "minscore_struct": None if (args.mode == "scores" or seq_only) else thr_struct,
+                "minscore_struct_source": None if (args.mode == "scores" or seq_only) else thr_note,
+                "hits_per_step": n_hits, "hits_per_step_all_ranks": sum(h for h in rank_hits if h is not None) if n_hits is not None else None,
+                "hit_rate": None if n_hits is None else n_hits / (windows * n_motifs),
                 "sharding": "records, no collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else "k_profile", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else "k_profile",
+                "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
+                "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": alg_bytes,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
-
+        if world > 1:
+            result["per_rank"] = {"kernel_ms": rank_ms, "parity_sample_ok": rank_ok,
+                                  "note": "no 1 -> N curve is claimed by this line: value = all ranks' windows / max-over-ranks time"}
         if args.mode == "hits2":
             # candidate-then-verify reads 1 B per position plus m rows per candidate: the fused-pass byte
             # count does not describe it, so no roofline figure is given for this mode
             result["roofline"] = None
+        if is_lib:
+            # The library pass is bound by LDS look-ups, not by HBM: every window x motif needs ceil(w/2) two-byte
+            # credits from the LDS tables (ds_read_b128, 256 B/clk/CU).  Beside it: the HBM fraction (codes once per
+            # pass + the structure rows of the candidates + hits) and the fp64 work of the verification.
+            info = library.info()
+            npair = (args.width + 1) // 2
+            lds_bytes = float(windows) * n_motifs * npair * 2
+            lds_peak = 256 * 256 * 2.4                      # CUs x B/clk/CU x GHz = GB/s (MI355X_MICROARCH.md, LDS)
+            cand = windows * n_motifs * rate_seq if thr_note != "given" else None
+            result["roofline"] = {
+                "bound": "lds", "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": lds_peak, "unit": "GB/s",
+                "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / lds_peak, "traffic": None, "traffic_source": None,
+                "kernel": "k_library (x%d passes of <= %d motifs)" % (info["passes"], info["motifs_per_pass"]),
+                "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
+                "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": lds_bytes,
+                "algorithmic_unit": "LDS look-up bytes: windows x motifs x ceil(w/2) x 2 B",
+                "hbm_frac": (args.records * args.length * info["passes"] + (cand or 0) * args.width * 28 + (n_hits or 0) * 24)
+                            / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "fp64_tflops_of_73_measured": None if cand is None else cand * args.width * 14 / (kernel_ms * 1e-3) / 1e12,
+                "prefilter_slack_score_units": info["max_prefilter_eps"],
+            }
         if world == 1 and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
             from oracle import oracle
             oracle.build()
@@ -313,11 +422,14 @@ def main():
             nrec = int(max(probe, min(args.records, probe * args.cpu_seconds / max(dt, 1e-6))))
             dt, ref_seq, ref_st = cpu_run(nrec)
             nwin = nrec * (args.length - args.width + 1)
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             result["cpu_baseline"] = {
                 "value": nwin / dt, "unit": "windows/s", "cores": oracle.num_threads(), "kind": "port",
                 "sample": "first %d of %d records (%d windows), oracle/pfm_oracle.c stream_seq + stream_struct_f32, "
                           "OpenMP over positions, %.2f s" % (nrec, args.records, nwin, dt),
-                "host_cpus": os.cpu_count(),
+                "host_cpus": os.cpu_count(), "usable_cpus": usable,
+                "cores_note": "OpenMP uses every CPU of this process's affinity mask (%d of the host's %d logical CPUs are "
+                              "usable by it); more threads than that would only time-share them" % (usable, os.cpu_count()),
             }
             got_seq = out_seq[: nrec * stride].cpu().numpy()
             got_st = out_st[: nrec * stride].cpu().numpy()
@@ -337,7 +449,7 @@ def main():
                 # pandas iloc + np.dot + nan_to_num, multiprocessing.Pool over records) on a
                 # small sample of the same records, scaled linearly in records (independent)
                 from oracle import ref_structured
-                cores = min(os.cpu_count() or 1, 128)
+                cores = min(usable, 128)
                 n_seq, n_st = cores * 4, cores
                 lut = np.array(list("ACGU") + ["N"] * 4)
                 seqs, profs = [], []

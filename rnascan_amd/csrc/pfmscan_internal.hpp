@@ -103,7 +103,7 @@ struct LibArgs {
     // one pass = nmp = 8 * ng motifs, tables laid out for the kernel (pfmscan_library_api.hip builds them)
     const uint32_t *pairs;                // [npair][ng][16][8] u16 two-letter credits, threshold folded into pair row 0
     const double *letters;                // [m * 4][nmp] fp64, transposed
-    const double *pssm;                   // [m * 7][nmp] fp64, transposed; null = no structure side
+    const double *pssm;                   // [m * 4][nmp][2] fp64: row j, column pair c/2, motif, c&1 (column 7 = 0); null = no structure side
     const double *thr_seq, *thr_struct;   // [nmp]
     int m, npair, nmp, ng, motif_base;
     // hits: LIB_SHARDS (or 1) regions of shard_cap slots, counters HIT_COUNTER_STRIDE words apart

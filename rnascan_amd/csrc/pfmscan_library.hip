@@ -26,7 +26,7 @@
 //      L1/L2), the motif's PSSM from LDS.  Hits are compacted inside the wave; one returning atomic per batch on
 //      one of 256 sharded counters.
 //
-// LDS per motif at width m: ceil(m/2)*32 B (credits) + m*32 B (fp64 letters) + m*56 B (fp64 structure PSSM)
+// LDS per motif at width m: (ceil(m/2)+1)*32 B (credits) + m*32 B (fp64 letters) + m*64 B (fp64 structure PSSM)
 // + 16 B thresholds; a library larger than the 160 KB allow is scanned in several passes (256 pairs of width 12:
 // passes of 96 / 96 / 64 motifs), each re-reading only the 1-byte codes.
 #include <float.h>
@@ -59,14 +59,17 @@ __device__ __forceinline__ uint32_t lib_codes4(const uint8_t *__restrict__ codes
 
 // structure score of the window at stream position p for pass-local motif mo: rows from global memory as
 // element-aligned 4-vectors (7 loads per 4 rows, see struct_score_at in pfmscan_kernels.hip), PSSM cells from the
-// transposed LDS copy pssm[(j*7+c)*NMP + mo] (neighbouring motifs 8 bytes apart: the distinct motifs of a wave
-// spread over the banks; NMP is a compile-time constant, so the cell offsets are immediates).
+// transposed LDS copy pssm[((j*4 + c/2)*NMP + mo)*2 + (c&1)] -- rows padded to 8 columns, two columns per 16 bytes, so
+// a row is four ds_read_b128 (as 8-byte reads hipcc pairs them into ds_read2_b64: twice the LDS cycles per value).
+// Neighbouring motifs are 16 bytes apart: the distinct motifs of a wave spread over the banks; NMP is a
+// compile-time constant, so the cell offsets are immediates.
 template <typename PROF_T, int NMP>
 __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t p, int m, const double *pssm_lds, int mo)
 {
     typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(profile) + p * 7;
-    const double *P = pssm_lds + mo;
+    const f64x2 *P = reinterpret_cast<const f64x2 *>(pssm_lds) + mo;
     double score = 0.0;
     for (int j0 = 0; j0 < m; j0 += 4) {
         PROF_T val[28];
@@ -90,10 +93,15 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
         for (int u = 0; u < 4; ++u) {
             const int j = base + u;
             if (j >= j0 && j < m) {
-                const double *Pj = P + (size_t)j * 7 * NMP;
-                double d = (double)val[u * 7] * Pj[0];
-#pragma unroll
-                for (int c = 1; c < 7; ++c) d = fma((double)val[u * 7 + c], Pj[c * NMP], d);
+                const f64x2 *Pj = P + (size_t)j * 4 * NMP;
+                const f64x2 p01 = Pj[0], p23 = Pj[NMP], p45 = Pj[2 * NMP], p67 = Pj[3 * NMP];
+                double d = (double)val[u * 7] * p01.x;
+                d = fma((double)val[u * 7 + 1], p01.y, d);
+                d = fma((double)val[u * 7 + 2], p23.x, d);
+                d = fma((double)val[u * 7 + 3], p23.y, d);
+                d = fma((double)val[u * 7 + 4], p45.x, d);
+                d = fma((double)val[u * 7 + 5], p45.y, d);
+                d = fma((double)val[u * 7 + 6], p67.x, d);
                 score += lib_nan_to_num(d);
             }
         }
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     uint32_t *pairs = reinterpret_cast<uint32_t *>(smem);
     double *letters = reinterpret_cast<double *>(smem + pair_bytes + NG * 256);
     double *pssm = letters + (size_t)m * 4 * NMP;
-    double *thr_s = pssm + (HAS_STRUCT ? (size_t)m * 7 * NMP : 0);
+    double *thr_s = pssm + (HAS_STRUCT ? (size_t)m * 8 * NMP : 0);
     double *thr_t = thr_s + NMP;
     uint32_t *qbase = reinterpret_cast<uint32_t *>(thr_t + NMP);
     uint32_t *q_pos = qbase + (size_t)wave * LIB_QCAP * (2 + CW);
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     for (int i = threadIdx.x; i < NG * 16; i += LIB_BLOCK) reinterpret_cast<u32x4 *>(pairs)[pair_bytes / 16 + i] = u32x4{0u, 0u, 0u, 0u};
     for (int i = threadIdx.x; i < m * 4 * NMP; i += LIB_BLOCK) letters[i] = a.letters[i];
     if (HAS_STRUCT)
-        for (int i = threadIdx.x; i < m * 7 * NMP; i += LIB_BLOCK) pssm[i] = a.pssm[i];
+        for (int i = threadIdx.x; i < m * 8 * NMP; i += LIB_BLOCK) pssm[i] = a.pssm[i];
     for (int i = threadIdx.x; i < NMP; i += LIB_BLOCK) {
         thr_s[i] = a.thr_seq[i];
         thr_t[i] = HAS_STRUCT ? a.thr_struct[i] : -INFINITY;
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 // LDS bytes of one pass (must match the carve-up in k_library)
 size_t lib_motif_bytes(int m, int npair, bool has_struct)
 {
-    return (size_t)(npair + 1) * 32 + (size_t)m * 32 + (has_struct ? (size_t)m * 56 : 0) + 16;     // +1: the zero row
+    return (size_t)(npair + 1) * 32 + (size_t)m * 32 + (has_struct ? (size_t)m * 64 : 0) + 16;     // +1: the zero row
 }
 
 size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * (2 + np_bucket / 8) * 4; }

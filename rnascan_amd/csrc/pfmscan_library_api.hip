@@ -165,14 +165,14 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
         ps.thr_off = thr_elems;
         pairs_elems += (size_t)ps.ng * npair * 16 * 8;
         letters_elems += (size_t)m * 4 * ps.nmp;
-        pssm_elems += (size_t)m * 7 * ps.nmp;
+        pssm_elems += (size_t)m * 8 * ps.nmp;
         thr_elems += (size_t)2 * ps.nmp;
         base += ps.n_real;
         lib->passes.push_back(ps);
     }
     lib->pairs_elems = pairs_elems;
     lib->thr_elems = thr_elems;
-    // transposed fp64 tables: [m * 4][nmp] letters, [m * 7][nmp] structure PSSM, per pass
+    // transposed fp64 tables per pass: [m * 4][nmp] letters; [m * 4][nmp][2] structure PSSM (rows padded to 8 columns)
     std::vector<double> hl(letters_elems, 0.0), hp(lib->has_struct ? pssm_elems : 0, 0.0);
     for (const LibPass &ps : lib->passes)
         for (int l = 0; l < ps.n_real; ++l) {
@@ -182,7 +182,7 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
                     hl[ps.letters_off + (size_t)(j * 4 + c) * ps.nmp + l] = letter_tables[((size_t)k * m + j) * 8 + c];
                 if (lib->has_struct)
                     for (int c = 0; c < 7; ++c)
-                        hp[ps.pssm_off + (size_t)(j * 7 + c) * ps.nmp + l] = struct_pssms[((size_t)k * m + j) * 7 + c];
+                        hp[ps.pssm_off + (((size_t)(j * 4 + c / 2)) * ps.nmp + l) * 2 + (c & 1)] = struct_pssms[((size_t)k * m + j) * 7 + c];
             }
         }
     hipError_t e = hipMalloc((void **)&lib->d_pairs, pairs_elems * 2);

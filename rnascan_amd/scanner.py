@@ -30,8 +30,12 @@ class HipEngine(object):
     def __init__(self, device=0):
         self.ctx = _lib.Context(device)
         self._staged = None
+        self._library = None        # (key, _lib.Library): the tables of the last library stay on the device across batches
 
     def close(self):
+        if self._library is not None:
+            self._library[1].close()
+            self._library = None
         self.ctx.close()
 
     def _stage(self, stream):
@@ -66,6 +70,25 @@ class HipEngine(object):
             return self.ctx.hits_staged(motif, thr_seq, thr_struct)
         finally:
             motif.close()
+
+
+def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None):
+    """hits of EVERY motif of a library in one pass over the stream (k_library): letter_tables [n][m][8],
+    struct_pssms [n][m][7] or None, thresholds scalar or [n] -> (pos, motif index, seq float32, struct float64 | None)
+    sorted by (pos, motif index)"""
+    T = np.ascontiguousarray(letter_tables, dtype=np.float64)
+    P = None if struct_pssms is None else np.ascontiguousarray(struct_pssms, dtype=np.float64)
+    key = (T.shape, T.tobytes(), None if P is None else P.tobytes())
+    if self._library is None or self._library[0] != key:
+        if self._library is not None:
+            self._library[1].close()
+            self._library = None
+        self._library = (key, self.ctx.library(T, P))
+    self._stage(stream)
+    return self.ctx.library_hits_staged(self._library[1], thr_seq, thr_struct)
+
+
+HipEngine.library_hits = _library_hits
 
 
 def _first_motif(pssm):
@@ -117,28 +140,46 @@ def scan_records(engine, records, pssm, letters, minscore):
         codes = [pack.encode_letters(s, order) for s in seqs]   # _py_calculate upper-cases, matrix.py:31
     stream = pack.pack(codes)                                  # packed (and staged on the device) once
     frames = []
-    for motif_id, pm in pssm.items():                          # the reference's dict only ever holds one (:262)
-        m = pm.length
-        table = pm.letter_table(order)
-        if is_rna:
-            pos, sq, _ = _select(engine, stream, m, table, None, float(minscore), -np.inf)
-            logodds = np.round(sq, 3)                          # round(np.float32, 3) stays float32 (rnascan.py:273)
-        else:
-            full = engine.scan_letters_f64(stream, table)       # Python floats in the reference: fp64, no f32 cast
-            keep = stream.window_mask(m) & (full > float(minscore))
-            pos = np.flatnonzero(keep)
-            logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
+
+    def rows(motif_ids, m, pos, mo, logodds):
         rec, start = stream.locate(pos)
         frag = [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
-        frames.append(pd.DataFrame({"_rec": rec, "Sequence_ID": [recs[r].id for r in rec.tolist()],
-                                    "Description": [recs[r].description for r in rec.tolist()], "Motif_ID": motif_id,
-                                    "Start": start + 1, "End": start + m, "Sequence": frag, "LogOdds": logodds}))
+        ids = motif_ids[0] if mo is None else np.asarray(motif_ids, dtype=object)[mo]
+        return pd.DataFrame({"_rec": rec, "Sequence_ID": [recs[r].id for r in rec.tolist()],
+                             "Description": [recs[r].description for r in rec.tolist()], "Motif_ID": ids,
+                             "Start": start + 1, "End": start + m, "Sequence": frag, "LogOdds": logodds})
+
+    # An RNA library with a finite threshold goes through the one-pass library kernel, one launch per PFM width
+    # (the reference's dict only ever holds one motif, rnascan.py:262).  Motifs are ordered by id, so
+    # the kernel's (position, motif index) order is the table's (Start, Motif_ID) order.
+    by_width = {}
+    for motif_id in sorted(pssm.keys()) if len(pssm) > 1 else list(pssm.keys()):
+        by_width.setdefault(pssm[motif_id].length, []).append(motif_id)
+    for m, ids in by_width.items():
+        if is_rna and len(ids) > 1 and np.isfinite(float(minscore)):
+            T = np.stack([pssm[i].letter_table(order) for i in ids])
+            pos, mo, sq, _ = engine.library_hits(stream, T, None, float(minscore))
+            frames.append(rows(ids, m, pos, mo, np.round(sq, 3)))
+            continue
+        for motif_id in ids:
+            table = pssm[motif_id].letter_table(order)
+            if is_rna:
+                pos, sq, _ = _select(engine, stream, m, table, None, float(minscore), -np.inf)
+                logodds = np.round(sq, 3)                      # round(np.float32, 3) stays float32 (rnascan.py:273)
+            else:
+                full = engine.scan_letters_f64(stream, table)   # Python floats in the reference: fp64, no f32 cast
+                keep = stream.window_mask(m) & (full > float(minscore))
+                pos = np.flatnonzero(keep)
+                logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
+            frames.append(rows([motif_id], m, pos, None, logodds))
     return _merge_motif_frames(frames)
 
 
 def _merge_motif_frames(frames):
     """one table per motif -> record order, then sort_values(['Start', 'Motif_ID']) inside a
     record (rnascan.py:286); with one motif this is the identity"""
+    if not frames:
+        return pd.DataFrame(columns=SEQ_COLUMNS)
     if len(frames) == 1:
         df = frames[0]
     else:
@@ -257,20 +298,41 @@ def combine(seq_results, struct_results):
     return result
 
 
+def pair_motifs(seq_pssm, struct_pssm):
+    """Which (sequence motif, structure motif) pairs a combined scan reports.  The reference only ever holds ONE
+    motif per side (rnascan.py:262, :298), where combine() (rnascan.py:422-423) joins their tables on
+    (Sequence_ID, Start, End).  For multi-PFM libraries (pfmutil.py:89-133):
+      * one motif on either side pairs with every motif of the other side (what the join gives);
+      * two libraries pair BY MOTIF ID (RNAcompete-S style: one sequence and one structure PFM per protein), by
+        position when no id is shared and the libraries have the same size;
+    and only pairs of equal width can share (Start, End).  Returns [(seq_id, struct_id)] sorted by the ids, or None
+    when two libraries of different size share no id (the caller then joins the two full tables)."""
+    sk, tk = list(seq_pssm.keys()), list(struct_pssm.keys())
+    if len(sk) == 1 or len(tk) == 1:
+        pairs = [(a, b) for a in sk for b in tk]
+    else:
+        shared = [a for a in sk if a in struct_pssm]
+        if shared:
+            pairs = [(a, a) for a in shared]
+        elif len(sk) == len(tk):
+            pairs = list(zip(sk, tk))
+        else:
+            return None
+    return sorted((a, b) for a, b in pairs if seq_pssm[a].length == struct_pssm[b].length)
+
+
 def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minscore, pairing="aligned",
                   profile_dtype=np.float32):
-    """Sequence PFM + averaged-structure PFM in ONE kernel pass (config 3).
+    """Sequence PFMs + averaged-structure PFMs in ONE pass per PFM width (configs 3 and 5).
 
     Equivalent to ``combine(scan_main(fasta), scan_main(dir))`` for the records
     that have a profile of the same length under the same Sequence_ID: a window
-    is reported iff seq > minscore AND struct > minscore (rnascan.py:422-433 is
-    an inner join of two independently thresholded tables).  Returns None when
-    the inputs cannot be paired one to one (duplicate ids, length mismatch,
-    unequal PFM widths); callers then take the two-table path."""
-    seq_id, spm = _first_motif(seq_pssm)
-    st_id, tpm = _first_motif(struct_pssm)
-    m = spm.length
-    if tpm.length != m:
+    is reported for the motif pair (a, b) iff seq_a > minscore AND struct_b > minscore
+    (rnascan.py:422-433 is an inner join of two independently thresholded tables); which pairs
+    exist is ``pair_motifs``.  Returns None when the inputs cannot be paired one to one (duplicate ids,
+    length mismatch, unpairable libraries); callers then take the two-table path."""
+    pairs_m = pair_motifs(seq_pssm, struct_pssm)
+    if pairs_m is None:
         return None
     recs = list(records)
     by_id = {}
@@ -281,7 +343,7 @@ def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minsco
     if len(set(r.id for r in recs)) != len(recs):
         return None
     pairs = [(r, by_id[r.id]) for r in recs if r.id in by_id]
-    if not pairs:
+    if not pairs or not pairs_m:
         return pd.DataFrame(columns=COMBINED_COLUMNS)
     letters0 = list(pairs[0][1][0])
     seqs, codes, profs = [], [], []
@@ -293,20 +355,41 @@ def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minsco
         codes.append(pack.encode_rna(s))
         profs.append(prof)
     stream = pack.pack(codes, profs, profile_dtype=profile_dtype)
-    table = spm.letter_table(pack.RNA_LETTERS)
-    P = struct_matrix(tpm, letters0, pairing)
-    pos, sq, st = _select(engine, stream, m, table, P, float(minscore), float(minscore))
-    rec, start = stream.locate(pos)
-    rl, sl = rec.tolist(), start.tolist()
-    lo_seq = np.round(sq, 3)
-    df = pd.DataFrame({
-        "Sequence_ID": [pairs[r][0].id for r in rl],
-        "Description.Seq": [pairs[r][0].description for r in rl],
-        "Motif_ID.Seq": seq_id, "Start": start + 1, "End": start + m,
-        "Sequence.Seq": [seqs[r][s:s + m] for r, s in zip(rl, sl)],
-        "LogOdds.Seq": lo_seq, "Description.Struct": "", "Motif_ID.Struct": st_id, "Sequence.Struct": ".",
-        "LogOdds.Struct": st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + st}, columns=COMBINED_COLUMNS)
-    return df
+    thr = float(minscore)
+    frames = []
+    by_width = {}
+    for a, b in pairs_m:
+        by_width.setdefault(seq_pssm[a].length, []).append((a, b))
+    for m, group in by_width.items():
+        tables = [seq_pssm[a].letter_table(pack.RNA_LETTERS) for a, _ in group]
+        pssms = [struct_matrix(struct_pssm[b], letters0, pairing) for _, b in group]
+        if len(group) > 1 and np.isfinite(thr):
+            pos, mo, sq, st = engine.library_hits(stream, np.stack(tables), np.stack(pssms), thr, thr)
+            parts = [(pos, mo, sq, st)]
+        else:
+            parts = []
+            for k in range(len(group)):
+                pos, sq, st = _select(engine, stream, m, tables[k], pssms[k], thr, thr)
+                parts.append((pos, np.full(pos.size, k, dtype=np.int32), sq, st))
+        for pos, mo, sq, st in parts:
+            rec, start = stream.locate(pos)
+            rl, sl = rec.tolist(), start.tolist()
+            lo_seq = np.round(sq, 3)
+            frames.append(pd.DataFrame({
+                "_rec": rec,
+                "Sequence_ID": [pairs[r][0].id for r in rl],
+                "Description.Seq": [pairs[r][0].description for r in rl],
+                "Motif_ID.Seq": np.asarray([a for a, _ in group], dtype=object)[mo], "Start": start + 1, "End": start + m,
+                "Sequence.Seq": [seqs[r][s:s + m] for r, s in zip(rl, sl)],
+                "LogOdds.Seq": lo_seq, "Description.Struct": "",
+                "Motif_ID.Struct": np.asarray([b for _, b in group], dtype=object)[mo], "Sequence.Struct": ".",
+                "LogOdds.Struct": st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + st}))
+    if len(frames) == 1:
+        df = frames[0]                      # (position, pair index) order = (record, Start, Motif_ID.Seq, Motif_ID.Struct)
+    else:
+        df = pd.concat(frames, ignore_index=True)
+        df = df.sort_values(["_rec", "Start", "Motif_ID.Seq", "Motif_ID.Struct"], kind="stable").reset_index(drop=True)
+    return df[COMBINED_COLUMNS]
 
 
 def _add_match_id(df):

@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+# the oracle's OpenMP loops run on arrays of a few thousand positions here: with one thread per visible CPU (128+ on
+# the GPU box, of which the job may use 16) every parallel region costs more in spin-waiting than the loop itself
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -20,5 +20,23 @@ class OracleEngine(object):
         pos = oracle.stream_hits(sq, st, thr_seq, thr_struct)
         return pos, (None if sq is None else sq[pos]), (None if st is None else st[pos])
 
+    def library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None):
+        """per-motif oracle scans -> (pos, motif, seq, struct | None) sorted by (pos, motif), like HipEngine.library_hits"""
+        n = letter_tables.shape[0]
+        ts = np.broadcast_to(np.asarray(thr_seq, dtype=np.float64), (n,))
+        tt = np.broadcast_to(np.asarray(-np.inf if thr_struct is None else thr_struct, dtype=np.float64), (n,))
+        pos, mo, sq_l, st_l = [], [], [], []
+        for k in range(n):
+            sq = oracle.stream_seq(stream.codes, letter_tables[k])
+            st = oracle.stream_struct(stream.profile, struct_pssms[k]) if struct_pssms is not None else None
+            p = oracle.stream_hits(sq, st, ts[k], tt[k] if st is not None else -np.inf)
+            pos.append(p)
+            mo.append(np.full(p.size, k, dtype=np.int32))
+            sq_l.append(sq[p])
+            st_l.append(st[p] if st is not None else np.zeros(p.size))
+        pos, mo, sq_l, st_l = np.concatenate(pos), np.concatenate(mo), np.concatenate(sq_l), np.concatenate(st_l)
+        order = np.lexsort((mo, pos))
+        return pos[order], mo[order], sq_l[order], (st_l[order] if struct_pssms is not None else None)
+
     def close(self):
         pass

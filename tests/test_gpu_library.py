@@ -19,30 +19,32 @@ def make_library(rng, n, m, inf_frac=0.0, struct=True):
 
 
 def oracle_library_hits(oracle, s, T, P, thr_seq, thr_struct):
-    """[(pos, motif, seq, struct)] sorted by (pos, motif) from per-motif oracle scans"""
+    """(pos, motif, seq, struct) arrays sorted by (pos, motif) from per-motif oracle scans"""
     n = T.shape[0]
-    rows = []
+    pos, mo, sq_l, st_l = [], [], [], []
     for k in range(n):
         sq = oracle.stream_seq(s.codes, T[k])
         st = oracle.stream_struct(s.profile, P[k]) if P is not None else None
-        pos = oracle.stream_hits(sq, st, thr_seq[k], thr_struct[k] if P is not None else -np.inf)
-        for p in pos.tolist():
-            rows.append((p, k, sq[p], st[p] if st is not None else np.nan))
-    rows.sort(key=lambda r: (r[0], r[1]))
-    return rows
+        p = oracle.stream_hits(sq, st, thr_seq[k], thr_struct[k] if P is not None else -np.inf)
+        pos.append(p)
+        mo.append(np.full(p.size, k, dtype=np.int32))
+        sq_l.append(sq[p])
+        st_l.append(st[p] if st is not None else np.full(p.size, np.nan))
+    pos, mo, sq_l, st_l = np.concatenate(pos), np.concatenate(mo), np.concatenate(sq_l), np.concatenate(st_l)
+    order = np.lexsort((mo, pos))
+    return pos[order], mo[order], sq_l[order], st_l[order]
 
 
 def check(got, want, has_struct):
     pos, mo, sq, st = got
-    assert len(pos) == len(want), "hit count %d, oracle %d" % (len(pos), len(want))
-    if not want:
+    wp, wm, wsq, wst = want
+    assert len(pos) == len(wp), "hit count %d, oracle %d" % (len(pos), len(wp))
+    if not len(wp):
         return
-    wp = np.array([r[0] for r in want], dtype=np.int64)
-    wm = np.array([r[1] for r in want], dtype=np.int32)
     assert np.array_equal(pos, wp) and np.array_equal(mo, wm)
-    assert_f32_bits_equal(sq, np.array([r[2] for r in want], dtype=np.float32))
+    assert_f32_bits_equal(sq, wsq)
     if has_struct:
-        assert_struct_close(st, np.array([r[3] for r in want], dtype=np.float64), tol=1e-6)
+        assert_struct_close(st, wst, tol=1e-6)
 
 
 def quantile_thresholds(oracle, s, T, P, q_seq, q_struct):
@@ -92,7 +94,7 @@ def test_library_hits_match_oracle_per_motif(ctx, oracle, n, m):
     ctx.stage(s.codes, s.profile)
     got = ctx.library_hits_staged(lib, ts, tt)
     want = oracle_library_hits(oracle, s, T, P, ts, tt)
-    assert len(want) > 20
+    assert len(want[0]) > 20
     check(got, want, True)
     info = lib.info()
     assert info["n_motifs"] == n and info["m"] == m and info["passes"] >= 1 and np.isfinite(info["max_prefilter_eps"])
@@ -108,7 +110,7 @@ def test_library_with_minus_inf_cells_and_f64_profile(ctx, oracle):
     lib = ctx.library(T, P)
     got = ctx.library_hits_host(lib, s.codes, s.profile, ts, tt)
     want = oracle_library_hits(oracle, s, T, P, ts, tt)
-    assert len(want) > 20
+    assert len(want[0]) > 20
     check(got, want, True)
     lib.close()
 
@@ -121,7 +123,7 @@ def test_sequence_only_library(ctx, oracle):
     lib = ctx.library(T, None)
     pos, mo, sq, st = ctx.library_hits_host(lib, s.codes, None, ts)
     want = oracle_library_hits(oracle, s, T, None, ts, None)
-    assert st is None and len(want) > 20
+    assert st is None and len(want[0]) > 20
     check((pos, mo, sq, st), want, False)
     lib.close()
 
@@ -208,7 +210,7 @@ def test_library_with_huge_and_plus_inf_log_odds(ctx, oracle):
     lib = ctx.library(T, P)
     got = ctx.library_hits_host(lib, s.codes, s.profile, ts, tt)
     want = oracle_library_hits(oracle, s, T, P, ts, tt)
-    assert len(want) > 20 and any(np.isinf(r[2]) for r in want)
+    assert len(want[0]) > 20 and np.isinf(want[2]).any()
     check(got, want, True)
     assert np.isinf(lib.info()["max_prefilter_eps"])
     lib.close()
@@ -227,7 +229,8 @@ def test_library_hits_dev_unordered_and_overflow(ctx, oracle):
     codes = torch.from_numpy(s.codes).to(dev)
     prof = torch.from_numpy(s.profile).to(dev)
     lib = ctx.library(T, P)
-    for cap in (len(want) + 7, max(len(want) // 3, 1)):
+    nwant = len(want[0])
+    for cap in (nwant + 7, max(nwant // 3, 1)):
         hp = torch.empty(cap, dtype=torch.int64, device=dev)
         hm = torch.empty(cap, dtype=torch.int32, device=dev)
         hs = torch.empty(cap, dtype=torch.float32, device=dev)
@@ -238,8 +241,8 @@ def test_library_hits_dev_unordered_and_overflow(ctx, oracle):
                              hp.data_ptr(), hm.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
         ctx.synchronize()
         k = int(cnt.item())
-        if cap >= len(want):
-            assert k == len(want)
+        if cap >= nwant:
+            assert k == nwant
             order = np.lexsort((hm[:k].cpu().numpy(), hp[:k].cpu().numpy()))
             check((hp[:k].cpu().numpy()[order], hm[:k].cpu().numpy()[order], hs[:k].cpu().numpy()[order],
                    ht[:k].cpu().numpy()[order]), want, True)
