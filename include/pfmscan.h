@@ -148,7 +148,7 @@ int pfmscan_hits_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
  * (1 byte per position) runs over everything and the structure score is computed only at
  * its hits (k_struct_at), because a combined hit needs BOTH thresholds (rnascan.py:422-433)
  * and the letter side is selective at real thresholds.  Falls back to the fused pass when
- * more than 1/16 of the windows pass the letter threshold.  Same hits, same scores. */
+ * more than 1/32 of the windows pass the letter threshold.  Same hits, same scores. */
 int pfmscan_hits_adaptive_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                               const uint8_t *d_codes, const void *d_profile,
                               int profile_dtype, int64_t n_pos, double thr_seq,

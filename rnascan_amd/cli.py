@@ -158,8 +158,8 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         fasta.eprint("Processed %d sequences" % len(files))
         return df
     fasta.eprint("Scanning sequences ")
-    recs = list(fasta.parse_sequences(source))
-    df = shard.scan_sharded(recs, [len(r.seq) for r in recs],
+    recs = fasta.LazyFasta(source)                     # index only: a rank / a batch reads just its own records
+    df = shard.scan_sharded(recs, recs.lengths,
                             lambda part: scanner.scan_records(engine, part, pssm, letters, args.minscore),
                             rank, world, dist, sink=sink)
     fasta.eprint("Processed %d sequences" % len(recs))
@@ -167,18 +167,19 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
 
 
 def _init_distributed(args):
-    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): records are
-    sharded over the ranks, no data-path collective; returns (rank, world, dist)."""
+    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): records are sharded over the ranks, there
+    is NO data-path collective; the only exchange is the host-side gather of the hit tables onto rank 0, so the
+    process group is gloo (RCCL moves nothing here; ``RNASCAN_DIST_BACKEND`` overrides).  Rank r scans on GPU
+    LOCAL_RANK.  Returns (rank, world, dist)."""
     rank, world = shard.env_rank_world()
     if world == 1:
         return 0, 1, None
-    import torch
     import torch.distributed as dist
-    backend = os.environ.get("RNASCAN_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RNASCAN_DIST_BACKEND", "gloo")
+    args.device = int(os.environ.get("LOCAL_RANK", str(args.device))) if os.environ.get("RNASCAN_ONE_DEVICE") != "1" else args.device
     if backend == "nccl":
-        torch.cuda.set_device(local)
-        args.device = local
+        import torch
+        torch.cuda.set_device(args.device)
     if not dist.is_initialized():
         dist.init_process_group(backend)
     return rank, world, dist
@@ -245,29 +246,58 @@ def main(argv=None, engine=None, out=None):
 
     streaming = world == 1 and not args.testseq
     if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
-        # sequence FASTA + averaged-structure directory: one fused kernel pass (config 3)
+        # sequence FASTA + averaged-structure directory (or packed store): one fused kernel pass per batch (configs 3, 5).
+        # Only an index of both sides is held; a batch reads its own records and the profiles of those records.
         ptype = np.dtype(args.profile_dtype).type
         fasta.eprint("Scanning sequences ")
-        recs = list(fasta.parse_sequences(seq_source))
+        recs = fasta.LazyFasta(seq_source)
         fasta.eprint("Processed %d sequences" % len(recs))
         fasta.eprint("Scanning averaged secondary structures ")
-        named = scanner.load_profile_dir(struct_source)
-        if len(named) == 0:
+        if store.is_store(struct_source):
+            ps = store.ProfileStore(struct_source)
+            where = {}
+            for i, sid in enumerate(ps.ids):
+                where.setdefault(sid, []).append(i)
+            n_prof = len(ps.ids)
+
+            def load(sid):
+                return [(sid, ps.letters, ps.profile[int(ps.offsets[i]):int(ps.offsets[i] + ps.lengths[i])]) for i in where.get(sid, [])]
+        else:
+            where = {}
+            for sid, path in fasta.list_profiles(struct_source):
+                where.setdefault(sid, []).append(path)
+            n_prof = sum(len(v) for v in where.values())
+
+            def load(sid):
+                out = []
+                for path in where.get(sid, []):
+                    file_letters, prof = fasta.read_profile(path)
+                    out.append((sid, file_letters, prof))
+                return out
+        if n_prof == 0:
             raise IOError("No averaged structure files found")
-        fasta.eprint("Processed %d sequences" % len(named))
-        lens = {sid: p.shape[0] for sid, _, p in named}
-        pairable = (len(lens) == len(named) and len(set(r.id for r in recs)) == len(recs)
-                    and all(lens.get(r.id, len(r.seq)) == len(r.seq) for r in recs)
-                    and len(set(tuple(l) for _, l, _ in named)) == 1)
-        if pairable:
-            final = shard.scan_sharded(
-                recs, [len(r.seq) for r in recs],
-                lambda part: scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore,
-                                                   args.pairing, ptype),
-                rank, world, dist, sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
-        else:                                  # ids / lengths do not pair one to one: two tables + join
+        fasta.eprint("Processed %d sequences" % n_prof)
+        unique = len(set(recs.ids)) == len(recs) and all(len(v) == 1 for v in where.values())
+
+        def scan_pairs(part):
+            """one batch: the fused pass when its records and profiles pair one to one (same id, same length, same
+            column order), else the reference's two tables + join for this batch (ids are unique, so the join of a
+            batch is the batch of the join)"""
+            named = [t for r in part for t in load(r.id)]
+            df = scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore, args.pairing, ptype)
+            if df is None:
+                df = scanner.combine(scanner.scan_records(eng, part, seq_pssm, fasta.RNA, args.minscore),
+                                     scanner.scan_profiles(eng, named, struct_pssm, args.minscore, args.pairing, ptype))
+                df = df[scanner.COMBINED_COLUMNS]
+            return df
+
+        if unique:
+            final = shard.scan_sharded(recs, recs.lengths, scan_pairs, rank, world, dist,
+                                       sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
+        else:                                  # duplicate ids join across records: two whole tables + join
+            named = [t for sid in where for t in load(sid)]
             seq_results = shard.scan_sharded(
-                recs, [len(r.seq) for r in recs],
+                recs, recs.lengths,
                 lambda part: scanner.scan_records(eng, part, seq_pssm, fasta.RNA, args.minscore), rank, world, dist)
             struct_results = shard.scan_sharded(
                 named, [p.shape[0] for _, _, p in named],

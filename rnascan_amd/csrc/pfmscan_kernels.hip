@@ -559,10 +559,14 @@ __device__ __forceinline__ double struct_window_slow(const PROF_T *prof_lds, int
 // `lds_base` must be wave-uniform: the hardware writes LDS[m0 + 16 * lane].
 __device__ __forceinline__ void dma_issue16(const void *gptr, uint32_t lds_base)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
-                 :
+    // M0 is written and restored inside ONE statement: hipcc reserves M0 and does not see an asm as a definition of
+    // it (an "m0" clobber only draws a warning), so a compiler-generated use of M0 scheduled across this statement
+    // must find its own value again.
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
                  : "v"(gptr), "s"(lds_base)
-                 : "memory");   // m0 is a reserved register: hipcc re-materialises it before each of its own uses
+                 : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t lds_addr(const void *p)

@@ -63,6 +63,95 @@ def parse_sequences(fasta_files):
                 yield _record(header, chunks)
 
 
+class LazyFasta(object):
+    """A FASTA file as a sliceable sequence of Records that holds only an INDEX in memory: id, header, byte offset and
+    letter count per record, from one cheap pass over the bytes.  ``lazy[a:b]`` seeks to record a and parses b - a
+    records, so a rank of a sharded run (shard.scan_sharded) reads only its own share and a batch only its own
+    records -- the reference hands every record to a pool worker through one iterator (rnascan.py:379-395).
+    Compressed input (.gz / .bz2) cannot be seeked: its records are parsed once and kept."""
+
+    def __init__(self, fasta_files):
+        self.files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
+        self.ids, self.headers, self.lengths = [], [], []
+        self._where = []                       # (file index, byte offset) per record, or a parsed Record
+        for fi, path in enumerate(self.files):
+            if os.path.splitext(path)[1] in (".gz", ".bz2"):
+                for rec in parse_sequences(path):
+                    self._add(rec.id, rec.description, len(rec.seq), rec)
+                continue
+            with open(path, "rb") as fh:
+                off, cur, n = 0, None, 0
+                for line in fh:
+                    if line.startswith(b">"):
+                        if cur is not None:
+                            self._add(cur[0], cur[1], n, (fi, cur[2]))
+                        header = line[1:].rstrip(b"\r\n").decode("utf-8", "replace")
+                        words = header.split(None, 1)
+                        cur, n = (words[0] if words else "", header, off), 0
+                    elif cur is not None:
+                        n += len(line.strip().replace(b" ", b""))
+                    off += len(line)
+                if cur is not None:
+                    self._add(cur[0], cur[1], n, (fi, cur[2]))
+
+    def _add(self, rid, header, n, where):
+        self.ids.append(rid)
+        self.headers.append(header)
+        self.lengths.append(n)
+        self._where.append(where)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def _read(self, lo, hi):
+        out = []
+        i = lo
+        while i < hi:
+            w = self._where[i]
+            if isinstance(w, Record):
+                out.append(w)
+                i += 1
+                continue
+            # the run of records lo.. that sit in the same file: one seek, parse until the run ends
+            fi, off = w
+            j = i
+            while j < hi and not isinstance(self._where[j], Record) and self._where[j][0] == fi:
+                j += 1
+            with open(self.files[fi], "rb") as fh:
+                fh.seek(off)
+                header, chunks, got = None, [], 0
+                for line in fh:
+                    if line.startswith(b">"):
+                        if header is not None:
+                            out.append(_record(header, chunks))
+                            got += 1
+                            if got == j - i:
+                                header = None
+                                break
+                        header, chunks = line[1:].rstrip(b"\r\n").decode("utf-8", "replace"), []
+                    elif header is not None:
+                        chunks.append(line.strip().decode("latin-1"))
+                if header is not None:
+                    out.append(_record(header, chunks))
+            i = j
+        return out
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            lo, hi, step = key.indices(len(self))
+            if step != 1:
+                raise ValueError("LazyFasta slices are contiguous")
+            return self._read(lo, max(lo, hi))
+        if key < 0:
+            key += len(self)
+        return self._read(key, key + 1)[0]
+
+    def __iter__(self):
+        for lo in range(0, len(self), 1024):
+            for rec in self._read(lo, min(len(self), lo + 1024)):
+                yield rec
+
+
 def _record(header, chunks):
     words = header.split(None, 1)
     rid = words[0] if words else ""

@@ -105,6 +105,59 @@ class PSSM(OrderedDict):
         """[m][len(columns)] matrix with the given letter per column."""
         return np.stack([self[l] for l in columns], axis=1)
 
+    # -- the two Biopython / BioAddons methods the reference's scan path calls, on the GPU ---------------------
+    def _is_rna(self):
+        return set(self.letters) == set("GAUC")
+
+    def calculate(self, sequence, engine=None):
+        """ExtendedPositionSpecificScoringMatrix.calculate (matrix.py:68-81): every window score of ``sequence``.
+        Nucleotide alphabets take the `_pwm.calculate` route (float32 ndarray, NaN for windows with a foreign letter,
+        matrix.py:57-60); other alphabets the `_py_calculate` one (list of Python floats, matrix.py:25-43).  A single
+        window gives a scalar (matrix.py:78-79)."""
+        from . import compat
+        engine = engine or compat.default_engine()
+        sequence = str(sequence)
+        m = self.length
+        if self._is_rna():
+            scores = engine.pwm_calculate(sequence, self.matrix(pack.RNA_LETTERS))
+        else:
+            stream = pack.pack([pack.encode_letters(sequence, self.letters)])
+            full = engine.scan_letters_f64(stream, self.letter_table(self.letters))
+            scores = [float(x) for x in full[:max(len(sequence) - m + 1, 0)]]
+        if len(scores) == 1:
+            return scores[0]
+        return scores
+
+    def search(self, sequence, threshold=0.0, both=False, engine=None):
+        """PositionSpecificScoringMatrix.search as rnascan.py:263 uses it: yields ``(position, score)`` for every
+        window with ``score > threshold`` (strict: NaN and -inf never pass), position 0-based, in window order; the
+        sequence is upper-cased first.  One launch for the whole sequence (pfmscan_hits_host) instead of one
+        `calculate` call per window.  ``both=True`` (reverse strand) is not part of the reference's call."""
+        if both:
+            raise ValueError("search(both=True) is not supported: rnascan only scans the given strand (rnascan.py:263)")
+        from . import compat
+        engine = engine or compat.default_engine()
+        sequence = str(sequence).upper()
+        m = self.length
+        threshold = float(threshold)
+        if self._is_rna():
+            stream = pack.pack([pack.encode_rna(sequence)])
+            table = self.letter_table(pack.RNA_LETTERS)
+            if np.isneginf(threshold):
+                sq, _ = engine.scan(stream, table, None)
+                pos = np.flatnonzero(stream.window_mask(m) & (sq.astype(np.float64) > threshold))
+                sc = sq[pos]
+            else:
+                pos, sc, _ = engine.hits(stream, table, None, threshold, -np.inf)
+            for p, x in zip(pos.tolist(), sc):
+                yield p, x                                  # numpy.float32, as calculate() returns it
+        else:
+            stream = pack.pack([pack.encode_letters(sequence, self.letters)])
+            full = engine.scan_letters_f64(stream, self.letter_table(self.letters))
+            keep = np.flatnonzero(stream.window_mask(m) & (full > threshold))
+            for p in keep.tolist():
+                yield p, float(full[p])
+
 
 def pfm2pssm(pfm_file, pseudocount, letters, background=None):
     """rnascan.py:238-252.  ``letters`` = alphabet.letters (the order Biopython

@@ -53,6 +53,11 @@ class HipEngine(object):
         finally:
             motif.close()
 
+    def pwm_calculate(self, sequence, matrix):
+        """``_pwm.calculate(sequence, matrix)`` (_pwm.c:79-121): str + float64 [m][4] (A,C,G,U) -> float32 [n]"""
+        self._staged = None
+        return self.ctx.pwm_calculate(sequence, matrix)
+
     def scan_letters_f64(self, stream, letter_table):
         """generic-alphabet letter scores in fp64 (matrix.py:25-43)"""
         motif = self.ctx.motif(letter_table, None)

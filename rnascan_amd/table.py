@@ -12,16 +12,25 @@ shard, one batch) at a time, without ever holding the whole table.
 import numpy as np
 
 
+def _quote(field):
+    """csv.QUOTE_MINIMAL as ``to_csv(sep='\\t')`` applies it (rnascan.py:559-567): a string field holding the
+    delimiter, the quote character or a line break is wrapped in double quotes, embedded quotes are doubled.
+    ``Description`` is the whole FASTA header, so this is reachable from ordinary input."""
+    if "\t" in field or '"' in field or "\n" in field or "\r" in field:
+        return '"' + field.replace('"', '""') + '"'
+    return field
+
+
 def _strings(col, n):
     """column -> list of n field strings, formatted the way pandas' to_csv does"""
     if isinstance(col, str):
-        return [col] * n
+        return [_quote(col)] * n
     if isinstance(col, (list, tuple)):
         if len(col) != n:
             raise ValueError("column length mismatch")
         if col and not isinstance(col[0], str):
             return _strings(np.asarray(col), n)
-        return list(col)
+        return [_quote(x) for x in col]
     a = np.asarray(col)
     if a.ndim == 0:
         return [_strings(a.reshape(1), 1)[0]] * n
@@ -35,7 +44,7 @@ def _strings(col, n):
         return s.tolist()
     if a.dtype.kind in "iu":
         return a.astype(str).tolist()
-    return [str(x) for x in a.tolist()]
+    return [_quote(x) if isinstance(x, str) else str(x) for x in a.tolist()]
 
 
 class TsvWriter(object):
@@ -46,7 +55,7 @@ class TsvWriter(object):
         self.columns = list(columns)
         self.match_id = match_id
         self.rows = 0
-        out.write("\t".join(self.columns + (["Match_ID"] if match_id else [])) + "\n")
+        out.write("\t".join([_quote(c) for c in self.columns] + (["Match_ID"] if match_id else [])) + "\n")
 
     def write_chunk(self, data, n=None):
         if n is None:

@@ -12,6 +12,9 @@ class OracleEngine(object):
         st = oracle.stream_struct(stream.profile, struct_pssm) if struct_pssm is not None else None
         return sq, st
 
+    def pwm_calculate(self, sequence, matrix):
+        return oracle.pwm_calculate(sequence, matrix)
+
     def scan_letters_f64(self, stream, letter_table):
         return oracle.stream_letters_f64(stream.codes, letter_table)
 

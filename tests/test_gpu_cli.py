@@ -201,3 +201,42 @@ def test_cli_batches_do_not_change_the_table(engine, tmp_path, monkeypatch):
     cli.main(argv, engine=engine, out=cut)
     assert whole.getvalue().count("\n") > 50
     assert cut.getvalue() == whole.getvalue()
+
+
+def test_compat_signatures_on_the_gpu(golden):
+    """PSSM.search / PSSM.calculate / scan_averaged_structure(struct_file, pssm, minscore) with the reference's
+    signatures on the HIP engine, against the reference-generated goldens"""
+    from rnascan_amd import scanner
+    from test_compat import check_compat
+    eng = scanner.HipEngine(0)
+    try:
+        check_compat(eng, golden)
+    finally:
+        eng.close()
+
+
+def test_cli_seq_and_struct_libraries_on_gpu(engine, tmp_path, monkeypatch):
+    """config 5's command line -- `rnascan -p seq_library -q struct_library fasta avgdir/` -- through the one-pass
+    library kernel: every motif pair of the libraries (18 pairs, mixed widths) on ragged records, the TSV equal to
+    the oracle-backed engine's (structure columns within 1e-6), also when cut into several batches"""
+    import io
+    from engines import OracleEngine
+    from rnascan_amd import cli
+    from test_scanner_cpu import _library_inputs, assert_tsv_equal
+    lib_s, lib_t, fa, d = _library_inputs(tmp_path)
+    argv = ["-p", lib_s, "-q", lib_t, "-u", "-C", "0.01", "-m", "-9", "--profile-dtype", "float64", fa, d]
+    want = io.StringIO()
+    cli.main(argv, engine=OracleEngine(), out=want)
+    got = io.StringIO()
+    cli.main(argv, engine=engine, out=got)
+    assert want.getvalue().count("\n") > 100
+    assert_tsv_equal(got.getvalue(), want.getvalue(), tol=1e-6)
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "700")
+    cut = io.StringIO()
+    cli.main(argv, engine=engine, out=cut)
+    assert cut.getvalue() == got.getvalue()
+    # a sequence-only library goes through the same kernel without the structure side
+    s_want, s_got = io.StringIO(), io.StringIO()
+    cli.main(["-p", lib_s, "-u", "-C", "0.01", "-m", "2", fa], engine=OracleEngine(), out=s_want)
+    cli.main(["-p", lib_s, "-u", "-C", "0.01", "-m", "2", fa], engine=engine, out=s_got)
+    assert s_got.getvalue() == s_want.getvalue() and s_want.getvalue().count("\n") > 50

@@ -220,3 +220,23 @@ def test_pack_locate_partition_properties():
         assert all(a <= b for a, b in parts) and all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
 
     run()
+
+
+def test_tsv_writer_quotes_like_to_csv():
+    """Description is the whole FASTA header: a tab, a double quote or a line break in it must be quoted exactly as
+    DataFrame.to_csv(sep='\\t') does (csv.QUOTE_MINIMAL, rnascan.py:559-567)"""
+    import io
+    import pandas as pd
+    from rnascan_amd import table
+    df = pd.DataFrame({
+        "Sequence_ID": ["a", "b", "c", "d"],
+        "Description": ['a desc\twith "tab"', 'plain', 'say "hi"', "two\nlines"],
+        "Motif_ID": ["m"] * 4, "Start": [1, 2, 3, 4], "End": [8, 9, 10, 11],
+        "Sequence": ["ACGUACGU"] * 4, "LogOdds": np.array([1.5, 2.25, np.nan, 7.125], dtype=np.float32)})
+    want = io.StringIO()
+    ref = df.copy()
+    ref["Match_ID"] = list(range(1, len(ref) + 1))
+    ref.to_csv(want, sep="\t", index=False)
+    got = io.StringIO()
+    table.write_frame(got, df, match_id=True)
+    assert got.getvalue() == want.getvalue()

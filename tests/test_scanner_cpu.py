@@ -246,3 +246,70 @@ def test_multi_pfm_library_equals_one_scan_per_motif(tmp_path):
     fa.write_text("".join(">%s\n%s\n" % (r.id, r.seq) for r in recs))
     cli.main(["-p", lib, "-u", "-C", "0.01", "-m", "1", str(fa)], engine=eng, out=out)
     assert len(out.getvalue().splitlines()) == len(both) + 1
+
+
+def _library_inputs(tmp_path, n_pairs=18, seed=5):
+    """two multi-PFM libraries (sequence + structure) sharing motif ids, mixed widths, and matching FASTA + profiles"""
+    rng = np.random.default_rng(seed)
+    seq_m, st_m = [], []
+    for k in range(n_pairs):
+        w = int(rng.choice([6, 8, 8, 12]))
+        seq_m.append(("RBP%02d" % k, list("ACGU"), rng.dirichlet(np.full(4, 0.5), size=w)))
+        st_m.append(("RBP%02d" % k, list("EHTBLRM"), rng.dirichlet(np.full(7, 0.5), size=w)))
+    st_m.append(("STRUCT_ONLY", list("EHTBLRM"), rng.dirichlet(np.full(7, 0.5), size=8)))      # no partner: never reported
+    lib_s, lib_t = str(tmp_path / "seq_lib.pfm"), str(tmp_path / "struct_lib.pfm")
+    _write_multi_pfm(lib_s, seq_m)
+    _write_multi_pfm(lib_t, st_m)
+    d = tmp_path / "avgdir"
+    d.mkdir()
+    fa = tmp_path / "recs.fa"
+    with open(fa, "w") as f:
+        for i in range(14):
+            L = int(rng.integers(0, 350))
+            f.write(">t%d transcript %d\n%s\n" % (i, i, "".join(rng.choice(list("ACGT"), size=L))))
+            with open(d / ("structure.t%d.txt" % i), "w") as g:
+                g.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+                p = rng.dirichlet(np.full(7, 0.3), size=L) if L else np.zeros((0, 7))
+                for j in range(L):
+                    g.write(str(j) + "\t" + "\t".join(repr(float(x)) for x in p[j]) + "\n")
+    return lib_s, lib_t, str(fa), str(d)
+
+
+def test_combined_scan_over_every_library_pair(tmp_path):
+    """N1 / config 5 productised: `-p seq_library -q struct_library fasta dir/` reports EVERY motif pair that shares an
+    id (one Motif_ID.Seq / Motif_ID.Struct per row), equal to scanning each pair on its own with the reference's
+    one-motif semantics (rnascan.py:262, :422-433) and merging the tables"""
+    lib_s, lib_t, fa, d = _library_inputs(tmp_path)
+    eng = OracleEngine()
+    ps = pssm.load_pssms(lib_s, 0.01, fasta.RNA, None)
+    pt = pssm.load_pssms(lib_t, 0.01, fasta.STRUCT, None)
+    assert len(ps) == 18 and len(pt) == 19
+    pairs = scanner.pair_motifs(ps, pt)
+    assert pairs == sorted((k, k) for k in ps) and ("STRUCT_ONLY", "STRUCT_ONLY") not in pairs
+    recs = list(fasta.parse_sequences(fa))
+    named = scanner.load_profile_dir(d)
+    lib = scanner.scan_combined(eng, recs, named, ps, pt, -9.0, "aligned", np.float64)
+    singles = [scanner.scan_combined(eng, recs, named, {a: ps[a]}, {b: pt[b]}, -9.0, "aligned", np.float64) for a, b in pairs]
+    want = pd.concat(singles, ignore_index=True)
+    rid = {r.id: i for i, r in enumerate(recs)}
+    want = want.assign(_r=want["Sequence_ID"].map(rid)).sort_values(["_r", "Start", "Motif_ID.Seq", "Motif_ID.Struct"], kind="stable")
+    assert len(lib) == len(want) > 100 and lib["Motif_ID.Seq"].nunique() > 10
+    pd.testing.assert_frame_equal(lib.reset_index(drop=True), want.drop(columns="_r").reset_index(drop=True))
+    # one structure motif against a library (and the reverse) = what the join of the two tables gives
+    one = {"RBP03": pt["RBP03"]}
+    widths = {k for k in ps if ps[k].length == pt["RBP03"].length}
+    got = scanner.scan_combined(eng, recs, named, ps, one, -9.0, "aligned", np.float64)
+    assert set(got["Motif_ID.Seq"]) <= widths and (got["Motif_ID.Struct"] == "RBP03").all() and len(got) > 20
+    join = scanner.combine(scanner.scan_records(eng, recs, ps, fasta.RNA, -9.0), scanner.scan_profiles(eng, named, one, -9.0, "aligned", np.float64))
+    assert len(join) == len(got)
+    a = join[scanner.COMBINED_COLUMNS].sort_values(["Sequence_ID", "Start", "Motif_ID.Seq"]).reset_index(drop=True)
+    b = got.sort_values(["Sequence_ID", "Start", "Motif_ID.Seq"]).reset_index(drop=True)
+    pd.testing.assert_frame_equal(a, b, check_dtype=False)
+    # through the command line
+    out = io.StringIO()
+    cli.main(["-p", lib_s, "-q", lib_t, "-u", "-C", "0.01", "-m", "-9", fa, d], engine=eng, out=out)
+    assert len(out.getvalue().splitlines()) == len(lib) + 1
+    # libraries of different size without a common id cannot be paired: the caller joins two tables
+    other = {"X" + k: v for k, v in list(pt.items())[:5]}
+    assert scanner.pair_motifs(ps, other) is None
+    assert scanner.scan_combined(eng, recs, named, ps, other, -9.0) is None

@@ -143,3 +143,83 @@ def test_sink_receives_the_batches_in_order(monkeypatch):
     assert ret is None and len(got) > 3
     cat = pd.concat([g for g in got if len(g)], ignore_index=True)
     pd.testing.assert_frame_equal(whole.reset_index(drop=True), cat)
+
+
+def _write_rnass_inputs(tmp_path, n=19, seed=3):
+    """a FASTA + a directory of averaged-structure profiles (pfmutil.py:61-87 format): most records pair one to one,
+    one has no profile, one profile has no record, one profile is SHORTER than its record (the batch holding it takes
+    the two-table join)"""
+    rng = np.random.default_rng(seed)
+    fa = tmp_path / "seqs.fa"
+    d = tmp_path / "avg"
+    d.mkdir()
+
+    def write_profile(sid, L):
+        with open(d / ("structure.%s.txt" % sid), "w") as f:
+            f.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+            p = rng.dirichlet(np.full(7, 0.3), size=L)
+            p[p < 0.02] = 0.0
+            for i in range(L):
+                f.write(str(i) + "\t" + "\t".join(repr(float(x)) for x in p[i]) + "\n")
+
+    with open(fa, "w") as f:
+        for i in range(n):
+            L = int(rng.integers(20, 260))
+            f.write(">rec%d the %dth record\n%s\n" % (i, i, "".join(rng.choice(list("ACGT"), size=L))))
+            if i == 4:
+                continue                                   # no profile for this record
+            write_profile("rec%d" % i, L - 7 if i == 9 else L)
+    write_profile("orphan", 50)
+    return str(fa), str(d)
+
+
+@pytest.mark.timeout(600)
+def test_cli_rnass_directory_and_store_under_two_gloo_ranks(tmp_path, monkeypatch):
+    """sequence FASTA + averaged-structure directory (config 3's command line), and the same through a packed profile
+    store: two ranks (each reading only its share of records and profiles) print what one rank prints"""
+    import io
+    import torch.multiprocessing as mp
+    from engines import OracleEngine
+    from rnascan_amd import cli, store
+    fa, d = _write_rnass_inputs(tmp_path)
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "900")    # several batches per rank
+    base = ["-p", os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt"),
+            "-q", os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", "-30"]
+    st = tmp_path / "packed"
+    store.build_store(d, str(st))
+    for tag, struct_arg in (("dir", d), ("store", str(st))):
+        argv = base + [fa, struct_arg]
+        single = io.StringIO()
+        cli.main(argv, engine=OracleEngine(), out=single)
+        assert single.getvalue().count("\n") > 30
+        out = tmp_path / tag
+        out.mkdir()
+        mp.spawn(_cli_worker, args=(2, _free_port(), str(out), argv), nprocs=2, join=True)
+        assert open(out / "out.0.tsv").read() == single.getvalue()
+        assert open(out / "out.1.tsv").read() == ""
+    # the two inputs describe the same profiles: same table up to the float64 text round trip of the store
+    # (directory and store rows come in FASTA order either way)
+
+
+def test_rnass_batches_equal_the_reference_join(tmp_path):
+    """the per-batch fused / fallback path == combine(scan_main(fasta), scan_main(dir)) over everything"""
+    import io
+    from engines import OracleEngine
+    from rnascan_amd import cli, fasta, pssm, scanner
+    fa, d = _write_rnass_inputs(tmp_path, n=12, seed=8)
+    base = ["-p", os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt"),
+            "-q", os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", "-30", fa, d]
+    got = io.StringIO()
+    cli.main(base, engine=OracleEngine(), out=got)
+    eng = OracleEngine()
+    ps = pssm.load_pssms(base[1], 0.01, fasta.RNA, None)
+    pt = pssm.load_pssms(base[3], 0.01, fasta.STRUCT, None)
+    seq = scanner.scan_records(eng, list(fasta.parse_sequences(fa)), ps, fasta.RNA, -30.0)
+    named = scanner.load_profile_dir(d)
+    order = {r.id: i for i, r in enumerate(fasta.parse_sequences(fa))}
+    named.sort(key=lambda t: order.get(t[0], 10 ** 9))
+    stt = scanner.scan_profiles(eng, named, pt, -30.0, "aligned", np.float64)
+    want = scanner.combine(seq, stt)
+    scanner._add_match_id(want)
+    assert got.getvalue() == want.to_csv(sep="\t", index=False)
+    assert len(want) > 30
