@@ -125,10 +125,18 @@ def main():
     ap.add_argument("--minscore-struct", type=float, default=None,
                     help="structure threshold of the hits modes [auto: the quantile of the structure scores of the windows "
                          "passing the sequence threshold that gives a combined hit rate of --hit-rate]")
+    ap.add_argument("--from-host", action="store_true",
+                    help="END-TO-END line instead of the device-resident one: the packed stream starts in pageable host memory "
+                         "(as a memory-mapped profile store does); a step = pfmscan_hits_pipeline_host: chunked upload on a copy "
+                         "stream beside the scan of the previous chunk, hits sorted and copied back.  Reports windows/s and the "
+                         "PCIe rate; never the headline value")
+    ap.add_argument("--chunk-positions", type=int, default=1 << 24, help="chunk of --from-host (stream positions)")
     ap.add_argument("--hit-rate", type=float, default=1e-4, help="target combined hit rate of the auto structure threshold (SURVEY 8d C5)")
     args = ap.parse_args()
     if args.minscore is not None:
         args.minscore_seq = args.minscore_struct = args.minscore
+    if args.from_host and args.mode == "scores":
+        args.mode = "hits"
 
     import torch
     from rnascan_amd import _lib
@@ -209,7 +217,10 @@ def main():
             thr_struct = -1e30
         else:
             srt, _ = torch.sort(sel)
-            thr_struct = float(srt[min(sel.numel() - 1, int((1.0 - keep) * sel.numel()))])
+            i = min(sel.numel() - 1, int((1.0 - keep) * sel.numel()))
+            # between two scores, never ON one: the kernels' structure sums differ in the last bit (FMA chain vs per-row
+            # sum), and a threshold equal to a score would let that bit decide a hit
+            thr_struct = float(srt[i]) if i == 0 else 0.5 * (float(srt[i - 1]) + float(srt[i]))
         thr_note = ("auto: quantile of the structure scores of the %.3g of windows with seq > %g (pooled over %d motif%s), for a "
                     "combined rate of %g" % (rate_seq, thr_seq, len(probe), "s" if len(probe) > 1 else "", args.hit_rate))
         del sel, pooled
@@ -226,7 +237,16 @@ def main():
         hit_st = torch.empty(cap, dtype=torch.float64, device=dev)
         hit_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    host_hits = [0]
+    if args.from_host:
+        codes_h = codes.cpu().numpy()
+        profile_h = None if seq_only else profile.cpu().numpy()
+
     def step():
+        if args.from_host:
+            pos, _, _ = ctx.hits_pipeline_host(motif, codes_h, profile_h, thr_seq, thr_struct, args.chunk_positions)
+            host_hits[0] = len(pos)
+            return
         if is_lib:
             ctx.library_hits_dev(library, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, thr_seq, thr_struct, cap,
                                  hit_pos.data_ptr(), hit_motif.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
@@ -280,7 +300,7 @@ def main():
     kernel_ms_rank = kernel_ms
     n_hits = None
     if args.mode != "scores":
-        n_hits = int(hit_count.item())
+        n_hits = host_hits[0] if args.from_host else int(hit_count.item())
 
     # ---- per-rank parity sample (multi-GPU runs): a few records of THIS rank's shard against the CPU oracle
     rank_parity = None
@@ -379,6 +399,16 @@ def main():
         if world > 1:
             result["per_rank"] = {"kernel_ms": rank_ms, "parity_sample_ok": rank_ok,
                                   "note": "no 1 -> N curve is claimed by this line: value = all ranks' windows / max-over-ranks time"}
+        if args.from_host:
+            h2d = args.records * (args.length + 1) * in_b
+            result["metric"] = "END-TO-END " + result["metric"] + " from pageable host memory (upload + scan + sorted hits back)"
+            result["roofline"] = None
+            result["host_path"] = {
+                "entry_point": "pfmscan_hits_pipeline_host", "chunk_positions": args.chunk_positions,
+                "h2d_bytes_per_step": h2d, "pcie_gbs": h2d / (elapsed / args.steps) / 1e9,
+                "pcie_reference_gbs": {"gen5_x16_spec": 63.0, "r1_stage_probe_measured": 56.0},
+                "note": "a step is bounded by the host-to-device copy; the device-resident kernel rate is the headline bench line",
+            }
         if args.mode == "hits2":
             # candidate-then-verify reads 1 B per position plus m rows per candidate: the fused-pass byte
             # count does not describe it, so no roofline figure is given for this mode

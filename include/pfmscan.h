@@ -173,6 +173,19 @@ int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                       double thr_struct, int64_t capacity, int64_t *hit_pos,
                       float *hit_seq, double *hit_struct, int64_t *n_hits);
 
+/* Hits of a host-resident stream of ANY length with bounded device scratch (a memory-mapped packed
+ * profile store is handed over as is; replaces the per-record `pd.read_table` + scan of rnascan.py:296-310 and the
+ * file fan-out of :351-366).  The stream is cut into chunks of chunk_positions (0 = 2^24) positions; the upload of
+ * chunk k+1 (copy stream) runs beside the scan of chunk k (two alternating device buffers), every chunk is one fused
+ * hits launch, hits come back sorted by stream position.  Same results and same capacity protocol as
+ * pfmscan_hits_host; nothing stays staged afterwards. */
+int pfmscan_hits_pipeline_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                               const uint8_t *codes, const void *profile,
+                               int profile_dtype, int64_t n_pos, int64_t chunk_positions,
+                               double thr_seq, double thr_struct, int64_t capacity,
+                               int64_t *hit_pos, float *hit_seq, double *hit_struct,
+                               int64_t *n_hits);
+
 /* ---- staged stream: upload once, scan with many motifs ------------------------
  * (multi-PFM libraries, SURVEY 8f N1: the reference reloads and rescans everything
  * per PFM file).  pfmscan_stage copies a packed stream into the ctx's device scratch

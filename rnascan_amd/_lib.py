@@ -32,6 +32,7 @@ SYMBOLS = [
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
+    "pfmscan_hits_pipeline_host",
 ]
 
 
@@ -108,6 +109,7 @@ def load():
     L.pfmscan_library_hits_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp]
     L.pfmscan_library_hits_staged.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy"):
@@ -248,6 +250,29 @@ class Context(object):
             self._check(rc, k.value)
             k = int(k.value)
             self._staged_n = n              # hits_host = stage + hits_staged: the stream stays staged
+            return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
+
+    def hits_pipeline_host(self, motif, codes, profile=None, thr_seq=-np.inf, thr_struct=-np.inf, chunk_positions=0,
+                           capacity=None):
+        """hits_host for streams of any length (numpy arrays or memory maps): chunked, the upload of the next chunk
+        overlaps the scan of the current one, device scratch = two chunks.  Same return values as hits_host."""
+        n, codes, profile, dt = _stream_args(motif, codes, profile)
+        cap = int(capacity) if capacity is not None else max(1024, n // 64)
+        self.scratch_gen += 1
+        self._staged_n = -1
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            sq = np.empty(cap, dtype=np.float32)
+            st = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_hits_pipeline_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n, int(chunk_positions),
+                                                    float(thr_seq), float(thr_struct), cap, _ptr(pos), _ptr(sq), _ptr(st),
+                                                    ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
             return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
 
     # -- staged stream: upload once, run many motifs ------------------------------------

@@ -2,17 +2,24 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the
 resulting ``rnascan_amd/libpfmscan.so`` travels to the GPU box with the tree.
+Every source is compiled to its own object (in parallel, only when it or a header
+changed), then linked.
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpfmscan.so")
-SOURCES = ["pfmscan_kernels.hip", "pfmscan_api.hip", "pfmscan_sort.hip", "pfmscan_library.hip", "pfmscan_library_api.hip"]
-DEPS = SOURCES + ["pfmscan_internal.hpp", "pfmscan_ctx.hpp", os.path.join("..", "..", "include", "pfmscan.h")]
+SOURCES = ["pfmscan_kernels.hip", "pfmscan_api.hip", "pfmscan_sort.hip", "pfmscan_library.hip", "pfmscan_library_api.hip",
+           "pfmscan_pipeline.hip"]
+HEADERS = ["pfmscan_internal.hpp", "pfmscan_ctx.hpp", os.path.join("..", "..", "include", "pfmscan.h")]
+DEPS = SOURCES + HEADERS
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall"]
 
 
 def hipcc_path():
@@ -29,16 +36,35 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+def _obj_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in [src] + HEADERS)
+
+
 def build_lib(force=False, verbose=False):
     """Compile the library when missing or older than its sources; return its path."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-fno-fast-math", "-Wall",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    hipcc = hipcc_path()
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        if force or _obj_stale(src, obj):
+            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
+        list(pool.map(run, jobs))
+    link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + \
+           [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    run(link)
     return LIB
 
 

@@ -176,7 +176,8 @@ def _init_distributed(args):
         return 0, 1, None
     import torch.distributed as dist
     backend = os.environ.get("RNASCAN_DIST_BACKEND", "gloo")
-    args.device = int(os.environ.get("LOCAL_RANK", str(args.device))) if os.environ.get("RNASCAN_ONE_DEVICE") != "1" else args.device
+    if os.environ.get("RNASCAN_ONE_DEVICE") != "1":      # "1": rehearsal of N ranks on a one-GPU box, every rank on --device
+        args.device = int(os.environ.get("LOCAL_RANK", str(args.device)))
     if backend == "nccl":
         import torch
         torch.cuda.set_device(args.device)

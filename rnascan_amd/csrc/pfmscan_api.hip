@@ -16,16 +16,6 @@
 
 using namespace pfmscan;
 
-struct pfmscan_motif {
-    pfmscan_ctx *ctx = nullptr;
-    double *d_letters = nullptr;   // [m][8]
-    float *d_pairs = nullptr;      // [(m+1)/2][16] two-letter fp32 sums (4-letter alphabets only), see k_letters_pre
-    double pair_eps = 0.0;
-    double *d_struct = nullptr;    // [m][7]
-    int m = 0;
-    int struct_finite = 0;
-};
-
 static thread_local std::string g_err;
 
 namespace pfmscan {
@@ -127,8 +117,13 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
                       &ctx->hit_seq, &ctx->hit_struct, &ctx->count, &ctx->table, &ctx->cand_pos, &ctx->cand_seq,
                       &ctx->cand_count, &ctx->sort_keys_in, &ctx->sort_keys_out, &ctx->sort_vals_in, &ctx->sort_vals_out,
                       &ctx->sort_temp, &ctx->sort_seq, &ctx->sort_struct, &ctx->hit_motif, &ctx->sort_motif, &ctx->lib_pos,
-                      &ctx->lib_motif, &ctx->lib_seq, &ctx->lib_struct, &ctx->lib_count})
+                      &ctx->lib_motif, &ctx->lib_seq, &ctx->lib_struct, &ctx->lib_count, &ctx->pipe_codes[0], &ctx->pipe_codes[1],
+                      &ctx->pipe_profile[0], &ctx->pipe_profile[1]})
         release(*b);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
+        if (ctx->pipe_scanned[i]) (void)hipEventDestroy(ctx->pipe_scanned[i]);
+    }
     delete ctx;
 }
 
@@ -229,7 +224,7 @@ void pfmscan_motif_destroy(pfmscan_motif *mo)
 }  // extern "C"
 
 // ---- shared argument checking + launch --------------------------------------
-static int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
+int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile,
                           int profile_dtype, int64_t n_pos, ScanArgs &a)
 {
     if (!ctx || !mo) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
@@ -257,12 +252,77 @@ static int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8
     return PFMSCAN_OK;
 }
 
-static int do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream)
+int pfmscan::do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream)
 {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const char *what = "";
     hipError_t e = launch_scan(a, ctx->tune, stream ? (hipStream_t)stream : ctx->stream, &what);
     if (e != hipSuccess) return fail_hip(ctx, e, what);
+    return PFMSCAN_OK;
+}
+
+// The ctx-owned sharded hit buffers (HIT_SHARDS regions of shard_cap slots, counters in ctx->count) -> the caller's host
+// arrays, sorted by position: capacity check, device sort (pfmscan_sort.hip), three contiguous copies.  Synchronises
+// ctx->stream.  Hit positions lie in [0, n_pos).
+int pfmscan::finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64_t n_pos, int64_t capacity, int64_t shard_cap,
+                                int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    int rc;
+    const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
+    std::vector<unsigned long long> counters((size_t)HIT_SHARDS * HIT_COUNTER_STRIDE);
+    HIP_TRY(ctx, hipMemcpyAsync(counters.data(), ctx->count.p, counter_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t total = 0, worst = 0;
+    for (int s = 0; s < HIT_SHARDS; ++s) {
+        total += counters[(size_t)s * HIT_COUNTER_STRIDE];
+        worst = std::max<uint64_t>(worst, counters[(size_t)s * HIT_COUNTER_STRIDE]);
+    }
+    *n_hits = (int64_t)total;
+    if ((int64_t)total > capacity || (int64_t)worst > shard_cap) {
+        // ask for enough that every shard fits next time
+        *n_hits = (int64_t)std::max<uint64_t>(total, worst * HIT_SHARDS);
+        return fail(ctx, PFMSCAN_E_CAPACITY, "hit buffer too small: " + std::to_string(total) + " hits, capacity " + std::to_string(capacity));
+    }
+    if (total == 0) return PFMSCAN_OK;
+    // shards -> one run in position order, on the device (pfmscan_sort.hip); three contiguous copies come back
+    int key_bits = 1;
+    while (key_bits < 63 && ((int64_t)1 << key_bits) < n_pos) ++key_bits;
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, sort_temp_bytes((int64_t)total, key_bits, &temp_bytes));
+    if ((rc = ensure(ctx, ctx->sort_keys_in, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_keys_out, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals_in, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals_out, total * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_temp, std::max<size_t>(temp_bytes, 256)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_seq, total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_struct, total * 8))) return rc;
+    GatherArgs g;
+    g.hit_pos = (const int64_t *)ctx->hit_pos.p;
+    g.hit_seq = mo->d_letters ? (const float *)ctx->hit_seq.p : nullptr;
+    g.hit_struct = mo->d_struct ? (const double *)ctx->hit_struct.p : nullptr;
+    g.counts = (const unsigned long long *)ctx->count.p;
+    g.shards = HIT_SHARDS;
+    g.shard_cap = shard_cap;
+    g.total = (int64_t)total;
+    g.key_bits = key_bits;
+    g.keys_in = (int64_t *)ctx->sort_keys_in.p;
+    g.keys_out = (int64_t *)ctx->sort_keys_out.p;
+    g.vals_in = (int64_t *)ctx->sort_vals_in.p;
+    g.vals_out = (int64_t *)ctx->sort_vals_out.p;
+    g.temp = ctx->sort_temp.p;
+    g.temp_bytes = ctx->sort_temp.cap;
+    g.seq_out = (float *)ctx->sort_seq.p;
+    g.struct_out = (double *)ctx->sort_struct.p;
+    {
+        hipError_t e = launch_gather_sorted(g, ctx->stream);
+        if (e != hipSuccess) return fail_hip(ctx, e, "gather + sort of the hits");
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(hit_pos, g.keys_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_seq && mo->d_letters) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_struct && mo->d_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hit_seq && !mo->d_letters) std::fill(hit_seq, hit_seq + total, NAN);
+    if (hit_struct && !mo->d_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
     return PFMSCAN_OK;
 }
 
@@ -554,61 +614,7 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, double thr_se
     HitSink sink = {(int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p, (double *)ctx->hit_struct.p,
                     (unsigned long long *)ctx->count.p, HIT_SHARDS, shard_cap};
     if ((rc = hits_core(ctx, mo, a, thr_seq, thr_struct, sink, ctx->stream, true))) return rc;
-    std::vector<unsigned long long> counters((size_t)HIT_SHARDS * HIT_COUNTER_STRIDE);
-    HIP_TRY(ctx, hipMemcpyAsync(counters.data(), ctx->count.p, counter_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t total = 0, worst = 0;
-    for (int s = 0; s < HIT_SHARDS; ++s) {
-        total += counters[(size_t)s * HIT_COUNTER_STRIDE];
-        worst = std::max<uint64_t>(worst, counters[(size_t)s * HIT_COUNTER_STRIDE]);
-    }
-    *n_hits = (int64_t)total;
-    if ((int64_t)total > capacity || (int64_t)worst > shard_cap) {
-        // ask for enough that every shard fits next time
-        *n_hits = (int64_t)std::max<uint64_t>(total, worst * HIT_SHARDS);
-        return fail(ctx, PFMSCAN_E_CAPACITY, "hit buffer too small: " + std::to_string(total) + " hits, capacity " + std::to_string(capacity));
-    }
-    if (total == 0) return PFMSCAN_OK;
-    // shards -> one run in position order, on the device (pfmscan_sort.hip); three contiguous copies come back
-    int key_bits = 1;
-    while (key_bits < 63 && ((int64_t)1 << key_bits) < n_pos) ++key_bits;
-    size_t temp_bytes = 0;
-    HIP_TRY(ctx, sort_temp_bytes((int64_t)total, key_bits, &temp_bytes));
-    if ((rc = ensure(ctx, ctx->sort_keys_in, total * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->sort_keys_out, total * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->sort_vals_in, total * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->sort_vals_out, total * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->sort_temp, std::max<size_t>(temp_bytes, 256)))) return rc;
-    if ((rc = ensure(ctx, ctx->sort_seq, total * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->sort_struct, total * 8))) return rc;
-    GatherArgs g;
-    g.hit_pos = (const int64_t *)ctx->hit_pos.p;
-    g.hit_seq = mo->d_letters ? (const float *)ctx->hit_seq.p : nullptr;
-    g.hit_struct = mo->d_struct ? (const double *)ctx->hit_struct.p : nullptr;
-    g.counts = (const unsigned long long *)ctx->count.p;
-    g.shards = HIT_SHARDS;
-    g.shard_cap = shard_cap;
-    g.total = (int64_t)total;
-    g.key_bits = key_bits;
-    g.keys_in = (int64_t *)ctx->sort_keys_in.p;
-    g.keys_out = (int64_t *)ctx->sort_keys_out.p;
-    g.vals_in = (int64_t *)ctx->sort_vals_in.p;
-    g.vals_out = (int64_t *)ctx->sort_vals_out.p;
-    g.temp = ctx->sort_temp.p;
-    g.temp_bytes = ctx->sort_temp.cap;
-    g.seq_out = (float *)ctx->sort_seq.p;
-    g.struct_out = (double *)ctx->sort_struct.p;
-    {
-        hipError_t e = launch_gather_sorted(g, ctx->stream);
-        if (e != hipSuccess) return fail_hip(ctx, e, "gather + sort of the hits");
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(hit_pos, g.keys_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (hit_seq && mo->d_letters) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (hit_struct && mo->d_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (hit_seq && !mo->d_letters) std::fill(hit_seq, hit_seq + total, NAN);
-    if (hit_struct && !mo->d_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
-    return PFMSCAN_OK;
+    return finish_sorted_hits(ctx, mo, n_pos, capacity, shard_cap, hit_pos, hit_seq, hit_struct, n_hits);
 }
 
 int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,

@@ -5,6 +5,16 @@
 
 #include "pfmscan_internal.hpp"
 
+struct pfmscan_motif {
+    pfmscan_ctx *ctx = nullptr;
+    double *d_letters = nullptr;   // [m][8]
+    float *d_pairs = nullptr;      // [(m+1)/2][16] two-letter fp32 sums (4-letter alphabets only), see k_letters_pre
+    double pair_eps = 0.0;
+    double *d_struct = nullptr;    // [m][7]
+    int m = 0;
+    int struct_finite = 0;
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -24,6 +34,8 @@ struct pfmscan_ctx {
     DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, sort_seq, sort_struct;   // pfmscan_sort.hip
     DevBuf hit_motif, sort_motif;               // library scans: motif index per hit
     DevBuf lib_pos, lib_motif, lib_seq, lib_struct, lib_count;   // library scans: sharded hits of the _dev form
+    DevBuf pipe_codes[2], pipe_profile[2];      // chunked host pipeline: double-buffered chunk of the stream
+    hipEvent_t pipe_copied[2] = {nullptr, nullptr}, pipe_scanned[2] = {nullptr, nullptr};
     // staged stream (pfmscan_stage)
     int64_t staged_n = -1;
     int staged_dtype = PFMSCAN_PROFILE_NONE;
@@ -38,6 +50,12 @@ int fail(pfmscan_ctx *ctx, int code, const std::string &msg);
 int fail_hip(pfmscan_ctx *ctx, hipError_t e, const char *what);
 int ensure(pfmscan_ctx *ctx, DevBuf &b, size_t bytes);
 void release(DevBuf &b);
+// pfmscan_api.hip: argument checks + ScanArgs of a scan of DEVICE buffers; launch on a stream; sharded hits -> sorted host arrays
+int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile, int profile_dtype,
+                   int64_t n_pos, ScanArgs &a);
+int do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream);
+int finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64_t n_pos, int64_t capacity, int64_t shard_cap,
+                       int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits);
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 }  // namespace pfmscan

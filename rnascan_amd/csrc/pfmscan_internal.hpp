@@ -36,6 +36,7 @@ struct ScanArgs {
     int hit_shards;                  // 1 (public _dev contract) or a power of two: workgroup b appends to shard
                                      // b & (hit_shards-1), i.e. to slots [shard*capacity, (shard+1)*capacity)
     int ablate;                  // timing diagnostics (PFMSCAN_ABLATE): 1 no scoring, 2 no staging, 4 no output
+    int64_t pos_offset;          // added to every reported hit position (chunked host pipeline: position of the chunk in the stream)
 };
 
 // Tuning knobs settable through the environment (read once per ctx), so that

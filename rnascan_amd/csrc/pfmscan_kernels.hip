@@ -164,7 +164,7 @@ __device__ __forceinline__ void emit_hits_block(const uint32_t passmask, PosF po
         for (int i = 0; i < N; ++i) {
             if (passmask & (1u << i)) {
                 if ((int64_t)slot < a.capacity) {                 // capacity is per shard
-                    a.hit_pos[off + slot] = pos_of(i);
+                    a.hit_pos[off + slot] = pos_of(i) + a.pos_offset;
                     if (a.hit_seq) a.hit_seq[off + slot] = seq_of(i);
                     if (a.hit_struct) a.hit_struct[off + slot] = st_of(i);
                 }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
 
     auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
         if ((int64_t)slot < a.capacity) {             // capacity is per shard
-            a.hit_pos[shard_off + slot] = pos;
+            a.hit_pos[shard_off + slot] = pos + a.pos_offset;
             if (a.hit_seq) a.hit_seq[shard_off + slot] = sc;
             if (a.hit_struct) a.hit_struct[shard_off + slot] = (double)sc;
         }

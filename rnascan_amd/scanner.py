@@ -19,6 +19,8 @@ from . import _lib, fasta, pack
 from .pssm import PSSM
 
 SEQ_COLUMNS = ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds"]
+PIPELINE_CHUNK = int(os.environ.get("RNASCAN_PIPELINE_CHUNK", str(1 << 24)))     # positions per chunk of the host pipeline
+PIPELINE_MIN = 2 * PIPELINE_CHUNK                                                 # shorter streams are staged whole
 
 
 class HipEngine(object):
@@ -68,9 +70,17 @@ class HipEngine(object):
             motif.close()
 
     def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf):
-        """positions (sorted) whose scores exceed the thresholds -> (pos, seq | None, struct | None)"""
+        """positions (sorted) whose scores exceed the thresholds -> (pos, seq | None, struct | None).
+        A stream that is not on the device yet and is longer than PIPELINE_MIN positions (a memory-mapped profile store,
+        a large batch) goes through the chunked pipeline: upload and scan overlap, device scratch stays two chunks."""
         motif = self.ctx.motif(letter_table, struct_pssm)
         try:
+            staged = self._staged is not None and self._staged[0] is stream and self._staged[1] == self.ctx.scratch_gen
+            if not staged and stream.n_pos > PIPELINE_MIN:
+                self._staged = None
+                return self.ctx.hits_pipeline_host(motif, stream.codes if letter_table is not None else None,
+                                                   stream.profile if struct_pssm is not None else None, thr_seq, thr_struct,
+                                                   PIPELINE_CHUNK)
             self._stage(stream)
             return self.ctx.hits_staged(motif, thr_seq, thr_struct)
         finally:

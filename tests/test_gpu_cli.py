@@ -151,10 +151,11 @@ def _gpu_cli_worker(rank, world, port, outdir, argv):
     from conftest import REPO
     sys.path.insert(0, REPO)
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RNASCAN_DIST_BACKEND": "gloo"})
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "RNASCAN_ONE_DEVICE": "1"})   # rehearsal on a one-GPU box: every rank on --device instead of LOCAL_RANK
     from rnascan_amd import cli
     with open(os.path.join(outdir, "out.%d.tsv" % rank), "w") as out:
-        cli.main(argv, out=out)                     # real HipEngine, one ctx per process
+        cli.main(argv, out=out)                     # real HipEngine, one ctx per process; process group = gloo (the default)
     import torch.distributed as dist
     dist.destroy_process_group()
 
@@ -240,3 +241,86 @@ def test_cli_seq_and_struct_libraries_on_gpu(engine, tmp_path, monkeypatch):
     cli.main(["-p", lib_s, "-u", "-C", "0.01", "-m", "2", fa], engine=OracleEngine(), out=s_want)
     cli.main(["-p", lib_s, "-u", "-C", "0.01", "-m", "2", fa], engine=engine, out=s_got)
     assert s_got.getvalue() == s_want.getvalue() and s_want.getvalue().count("\n") > 50
+
+
+def test_profile_store_on_gpu(engine, golden, tmp_path):
+    """N2 on the device: structure.<id>.txt directory -> packed store (rnascan-pack-profiles) -> scanned as mapped, equal to
+    the reference's own scan_main directory-branch output, to the directory scan, and through the command line"""
+    import io
+    import shutil
+    from engines import OracleEngine
+    from rnascan_amd import cli, fasta, pssm, scanner, store
+    d = tmp_path / "avg"
+    d.mkdir()
+    shutil.copyfile(os.path.join(DATA_DIR, "HIST2H3C_3p_end_structure.txt"), d / "structure.hg19_dna.txt")
+    st = str(tmp_path / "packed")
+    assert store.build_store(str(d), st, np.float64) == 1
+    P = {"SLBP_struct": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    ps = store.ProfileStore(st)
+    df = scanner.scan_store(engine, ps, P, 0.0, "aligned")
+    g = golden["scan_main_dir"]
+    got = [[r[0], r[1], r[2], int(r[3]), int(r[4]), r[5], float(r[6])] for r in df.itertuples(index=False)]
+    assert list(df.columns) == g["columns"] and len(got) == len(g["rows"])
+    for a, b in zip(got, g["rows"]):
+        assert a[:6] == b[:6] and abs(a[6] - b[6]) <= 1e-6
+    # ragged synthetic directory: store scan (HIP) == directory scan (HIP) == store scan (oracle engine)
+    rng = np.random.default_rng(4)
+    d2 = tmp_path / "avg2"
+    d2.mkdir()
+    for i in range(23):
+        L = int(rng.integers(0, 400))
+        with open(d2 / ("structure.s%02d.txt" % i), "w") as f:
+            f.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+            p = rng.dirichlet(np.full(7, 0.3), size=L) if L else np.zeros((0, 7))
+            for j in range(L):
+                f.write(str(j) + "\t" + "\t".join(repr(float(x)) for x in p[j]) + "\n")
+    st2 = str(tmp_path / "packed2")
+    store.build_store(str(d2), st2, np.float32)
+    ps2 = store.ProfileStore(st2)
+    a = scanner.scan_store(engine, ps2, P, -40.0, "aligned")
+    b = scanner.scan_store(OracleEngine(), ps2, P, -40.0, "aligned")
+    assert len(a) == len(b) > 50
+    assert a.drop(columns="LogOdds").equals(b.drop(columns="LogOdds")) and np.abs(a["LogOdds"] - b["LogOdds"]).max() <= 1e-6
+    named = sorted(scanner.load_profile_dir(str(d2)), key=lambda t: t[0])
+    c = scanner.scan_profiles(engine, named, P, -40.0, "aligned", np.float32)
+    assert a.drop(columns="LogOdds").equals(c.drop(columns="LogOdds")) and np.abs(a["LogOdds"] - c["LogOdds"]).max() <= 1e-6
+    o1, o2 = io.StringIO(), io.StringIO()
+    cli.main(["-q", STRUCT_PFM, "-u", "-C", "0.01", "-m", "-40", st2], engine=engine, out=o1)
+    cli.main(["-q", STRUCT_PFM, "-u", "-C", "0.01", "-m", "-40", st2], engine=OracleEngine(), out=o2)
+    assert_rows = lambda t: [l.split("\t") for l in t.splitlines()]     # noqa: E731
+    r1, r2 = assert_rows(o1.getvalue()), assert_rows(o2.getvalue())
+    assert len(r1) == len(r2) == len(a) + 1
+    for x, y in zip(r1[1:], r2[1:]):
+        assert x[:6] == y[:6] and x[7] == y[7] and abs(float(x[6]) - float(y[6])) <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["both", "seq", "struct"])
+def test_host_pipeline_equals_staged_hits(ctx, oracle, kind):
+    """pfmscan_hits_pipeline_host (chunks, upload of chunk k+1 beside the scan of chunk k) == pfmscan_hits_host == oracle,
+    with chunk borders inside records and inside windows, for every kind of motif"""
+    from test_gpu_parity import rand_stream, rand_struct_pssm, rand_table
+    rng = np.random.default_rng({"both": 1, "seq": 2, "struct": 3}[kind])
+    s = rand_stream(rng, 150, 0, 2000, foreign=0.003)
+    m = 12
+    T = rand_table(rng, m, 4) if kind != "struct" else None
+    P = rand_struct_pssm(rng, m, inf_frac=0.1) if kind != "seq" else None
+    motif = ctx.motif(T, P)
+    thr_s, thr_t = (0.0, -30.0)
+    want = ctx.hits_host(motif, s.codes if T is not None else None, s.profile if P is not None else None, thr_s, thr_t)
+    assert len(want[0]) > 100
+    for chunk in (4096, 5120, 65536, 1 << 22):
+        got = ctx.hits_pipeline_host(motif, s.codes if T is not None else None, s.profile if P is not None else None, thr_s, thr_t, chunk)
+        assert np.array_equal(got[0], want[0])
+        if T is not None:
+            assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+        if P is not None:
+            assert np.abs(got[2] - want[2]).max() <= 1e-6
+    # against the oracle (sequence side decides the positions when there is one)
+    sq = oracle.stream_seq(s.codes, T) if T is not None else None
+    st = oracle.stream_struct(s.profile, P) if P is not None else None
+    assert np.array_equal(want[0], oracle.stream_hits(sq, st, thr_s, thr_t))
+    from rnascan_amd import _lib
+    with pytest.raises(_lib.CapacityError) as ei:
+        ctx.hits_pipeline_host(motif, s.codes if T is not None else None, s.profile if P is not None else None, thr_s, thr_t, 4096, capacity=5)
+    assert ei.value.required >= len(want[0])
+    motif.close()
