@@ -125,3 +125,167 @@ def test_fullsize_properties(big, oracle):
         assert np.array_equal(sq[: L - M + 1].view(np.uint32), ref_sq[: L - M + 1].view(np.uint32))
         assert np.abs(st[: L - M + 1] - ref_st[: L - M + 1]).max() <= 1e-6
     motif.close()
+
+
+def test_fullsize_c2_sequence_only(big, oracle):
+    """BASELINE configs[1] at full size: 100k x 3 kb, sequence PFM of width 8, all-scores through
+    k_letters<5, float, false, 8> (73k workgroups): deterministic, x2 exact, NaN exactly at the separator-touching
+    windows, 64 sampled records equal to the oracle bit for bit"""
+    import bench
+    torch = big["torch"]
+    from rnascan_amd import _lib
+    m = 8
+    table, _ = bench.make_pssms(m)
+    ctx, codes, n_pos, dev = big["ctx"], big["codes"], big["n_pos"], big["dev"]
+
+    def scan(tab):
+        out = torch.empty(n_pos, dtype=torch.float32, device=dev)
+        motif = ctx.motif(letter_table=tab)
+        ctx.scan_dev(motif, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, out.data_ptr(), None)
+        ctx.synchronize()
+        motif.close()
+        return out
+
+    s1, s1b = scan(table), scan(table)
+    assert torch.equal(s1.view(torch.int32), s1b.view(torch.int32))
+    del s1b
+    assert int(torch.isnan(s1).sum()) == R * m                  # the m windows per record that touch its separator
+    s2 = scan(2.0 * table)
+    ok = ~torch.isnan(s1)
+    assert torch.equal(s2[ok], 2.0 * s1[ok])
+    del s2, ok
+    rng = np.random.default_rng(1)
+    stride = L + 1
+    for r in rng.choice(R, size=64, replace=False):
+        lo = int(r) * stride
+        c = codes[lo:lo + stride].cpu().numpy()
+        ref = oracle.stream_seq(c, table)
+        got = s1[lo:lo + stride].cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        v = ~np.isnan(ref)
+        assert np.array_equal(got[v].view(np.uint32), ref[v].view(np.uint32))
+    # hits mode over the same stream (k_letters_pre) == thresholding the all-scores output
+    motif = ctx.motif(letter_table=table)
+    want = torch.nonzero(s1.double() > 6.0).flatten()
+    cap = int(want.numel()) + 16
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.hits_dev(motif, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, 6.0, -np.inf, cap, hp.data_ptr(), hs.data_ptr(), None, cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    assert k == int(want.numel()) and k > 1000
+    order = torch.argsort(hp[:k])
+    assert torch.equal(hp[:k][order], want) and torch.equal(hs[:k][order], s1[want])
+    motif.close()
+
+
+def test_fullsize_c5_library_equals_all_scores(big, oracle):
+    """BASELINE configs[4] at full size: 256 seq+struct PFM pairs over the 100k x 3 kb stream through the one-pass library
+    kernel (three passes of 96 / 96 / 64 motifs).  For motifs of every pass the library's hits are exactly the windows
+    the all-scores kernel puts above both thresholds: same positions, same float32 sequence scores, structure scores
+    within 1e-6; and the total matches the sum over ALL motifs of a thresholded count (no motif is skipped)"""
+    import bench
+    torch = big["torch"]
+    from rnascan_amd import _lib
+    ctx, codes, profile, n_pos, dev = big["ctx"], big["codes"], big["profile"], big["n_pos"], big["dev"]
+    n = 256
+    tabs = [bench.make_pssms(M, "finite", seed=1000 + k) for k in range(n)]
+    lib = ctx.library(np.stack([t for t, _ in tabs]), np.stack([p for _, p in tabs]))
+    thr_s, thr_t = 6.0, -5.03125
+    cap = 1 << 25
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hm = torch.empty(cap, dtype=torch.int32, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    ht = torch.empty(cap, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.library_hits_dev(lib, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, thr_s, thr_t, cap,
+                         hp.data_ptr(), hm.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    assert 1000000 < k <= cap
+    assert lib.info()["passes"] == 3
+    per_motif = torch.bincount(hm[:k].long(), minlength=n)
+    assert int(per_motif.min()) > 0                              # every motif of every pass reports hits
+    out_seq = torch.empty(n_pos, dtype=torch.float32, device=dev)
+    out_st = torch.empty(n_pos, dtype=torch.float64, device=dev)
+    for mk in (0, 95, 96, 191, 192, 255):                         # first / last motif of each pass
+        motif = ctx.motif(*tabs[mk])
+        ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, out_seq.data_ptr(), out_st.data_ptr())
+        ctx.synchronize()
+        motif.close()
+        want = torch.nonzero((out_seq.double() > thr_s) & (out_st > thr_t)).flatten()
+        sel = torch.nonzero(hm[:k] == mk).flatten()
+        assert int(sel.numel()) == int(want.numel()) == int(per_motif[mk])
+        order = torch.argsort(hp[:k][sel])
+        idx = sel[order]
+        assert torch.equal(hp[:k][idx], want)
+        assert torch.equal(hs[:k][idx].view(torch.int32), out_seq[want].view(torch.int32))
+        assert float((ht[:k][idx] - out_st[want]).abs().max()) <= 1e-6
+    lib.close()
+
+
+def test_fullsize_c4_shard_of_125k_records(oracle):
+    """one shard of BASELINE configs[3] (1M records over 8 GPUs = 125k x 3 kb per GPU, 375M positions): deterministic,
+    NaN pattern, x2 exactness, hits == thresholded scores, 32 sampled records against the oracle"""
+    import torch
+    import bench
+    from rnascan_amd import _lib
+    if torch.cuda.mem_get_info()[0] < 60e9:
+        pytest.skip("needs 60 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    R4 = 125000
+    ctx = _lib.Context(0)
+    table, spssm = bench.make_pssms(M)
+    codes, profile, n_pos = bench.make_stream(torch, dev, R4, L, 20240601 + 3)      # rank 3's stream of the bench
+    torch.cuda.synchronize()
+    motif = ctx.motif(table, spssm)
+
+    def scan(mo):
+        a = torch.empty(n_pos, dtype=torch.float32, device=dev)
+        b = torch.empty(n_pos, dtype=torch.float64, device=dev)
+        ctx.scan_dev(mo, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, a.data_ptr(), b.data_ptr())
+        ctx.synchronize()
+        return a, b
+
+    s1, t1 = scan(motif)
+    s1b, t1b = scan(motif)
+    assert torch.equal(s1.view(torch.int32), s1b.view(torch.int32)) and torch.equal(t1.view(torch.int64), t1b.view(torch.int64))
+    del s1b, t1b
+    assert int(torch.isnan(s1).sum()) == R4 * M
+    m2 = ctx.motif(2.0 * table, 2.0 * spssm)
+    s2, t2 = scan(m2)
+    m2.close()
+    ok = ~torch.isnan(s1)
+    assert torch.equal(s2[ok], 2.0 * s1[ok]) and torch.equal(t2[: n_pos - M], 2.0 * t1[: n_pos - M])
+    del s2, t2, ok
+    thr_s, thr_t = 5.0, -9.0
+    want = torch.nonzero((s1.double() > thr_s) & (t1 > thr_t)).flatten()
+    cap = int(want.numel()) + 16
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    ht = torch.empty(cap, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.hits_adaptive_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, thr_s, thr_t, cap,
+                          hp.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    assert k == int(want.numel()) and k > 100
+    order = torch.argsort(hp[:k])
+    assert torch.equal(hp[:k][order], want) and torch.equal(hs[:k][order], s1[want])
+    assert float((ht[:k][order] - t1[want]).abs().max()) <= 1e-6
+    rng = np.random.default_rng(4)
+    stride = L + 1
+    for r in rng.choice(R4, size=32, replace=False):
+        lo = int(r) * stride
+        c = codes[lo:lo + stride].cpu().numpy()
+        p = profile[lo:lo + stride].cpu().numpy()
+        ref_sq, ref_st = oracle.stream_seq(c, table), oracle.stream_struct(p, spssm)
+        got_sq, got_st = s1[lo:lo + L - M + 1].cpu().numpy(), t1[lo:lo + L - M + 1].cpu().numpy()
+        assert np.array_equal(got_sq.view(np.uint32), ref_sq[: L - M + 1].view(np.uint32))
+        assert np.abs(got_st - ref_st[: L - M + 1]).max() <= 1e-6
+    motif.close()
+    ctx.close()

@@ -205,7 +205,9 @@ def test_scan_averaged_structure_goldens(ctx, golden, data_dir):
         s32 = pack.pack(profiles=[prof], profile_dtype=np.float32)
         _, got32 = ctx.scan_host(motif, None, s32.profile)
         got32 = got32[: prof.shape[0] - m + 1]
-        assert_struct_close(got32[keep], np.array([r[2] for r in want]), tol=2e-6)
+        # north_star's 1e-6: float32 storage of the reference's own example stays inside it (8.6e-7 at |score| <= 37); it
+        # leaves the tolerance for wider PFMs / larger |log-odds|, where --profile-dtype float64 is the answer
+        assert_struct_close(got32[keep], np.array([r[2] for r in want]), tol=1e-6)
         motif.close()
 
 
