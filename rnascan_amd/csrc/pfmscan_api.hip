@@ -97,6 +97,7 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     if (const char *v = std::getenv("PFMSCAN_TWO_PHASE")) ctx->tune.two_phase = std::atoi(v) != 0;
     if (const char *v = std::getenv("PFMSCAN_TILES_PER_BLOCK")) ctx->tune.tiles_per_block = std::max(0, std::min(1024, std::atoi(v)));
     if (const char *v = std::getenv("PFMSCAN_PREFILTER")) ctx->tune.prefilter = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_CREDITS")) ctx->tune.credits = std::atoi(v) != 0;
     *out = ctx;
     return PFMSCAN_OK;
 }
@@ -191,6 +192,10 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
             }
             // rounding of the entries + of the fp32 adds + of the exact score's float cast <= ~4e-6 * bound at 32 pairs
             mo->pair_eps = bound * 0x1p-17 + 1e-30;
+            if (four && m <= 16) {
+                pair_sums(letter_table, m, mo->h_pairsum);
+                mo->has_pairsum = true;
+            }
             if (four) e = hipMalloc((void **)&mo->d_pairs, sizeof(float) * pairs.size());
             if (four && e == hipSuccess) e = hipMemcpy(mo->d_pairs, pairs.data(), sizeof(float) * pairs.size(), hipMemcpyHostToDevice);
         }
@@ -245,6 +250,7 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.letter_table = mo->d_letters;
     a.pair_table = ctx->tune.prefilter ? mo->d_pairs : nullptr;
     a.pair_eps = mo->pair_eps;
+    a.h_pairsum = mo->has_pairsum ? mo->h_pairsum : nullptr;
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;

@@ -18,6 +18,8 @@ struct ScanArgs {
     int tiles_per_block;         // k_letters_pre: consecutive tiles one workgroup walks (set by the launcher)
     float thr_pre;               // k_letters_pre: largest float <= thr_seq - pair_eps (set by the launcher)
     double pair_eps;             // |fp32 pair-table score - exact score| <= pair_eps for every window
+    const double *h_pairsum;     // HOST: [(m+1)/2][16] exact two-letter sums (4-letter alphabets): the launcher builds the
+                                 // integer credit table of k_letters_cred from them for the call's threshold
     const double *struct_pssm;   // [m][7] device or null
     int m;
     int struct_finite;           // every struct_pssm cell finite -> fast path legal
@@ -52,9 +54,17 @@ struct Tuning {
     int prefilter = 1;      // hits over 4-letter alphabets: fp32 two-letter prefilter, exact fp64 re-score of survivors
     int tiles_per_block = 0; // k_letters_pre: 0 = pick from the stream length; > 0 forces it (PFMSCAN_TILES_PER_BLOCK, tests)
     int two_phase = 1;      // combined hits through the host/staged API: letters first, structure only at candidates
+    int credits = 1;        // hits over 4-letter alphabets, m <= 16: integer position-keyed prefilter (k_letters_cred) instead of
+                            // the fp32 one (k_letters_pre); PFMSCAN_CREDITS=0 for A/B runs and tests
 };
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);
+
+// Credits of ONE motif at threshold thr (pfmscan_library_api.hip): pairsum [npair][16] exact two-letter sums ->
+// out [npair][16] unsigned 16-bit credits with the threshold folded into row 0; "bit 15 of the sum clear" => the
+// window cannot be a hit.  Returns the one-sided slack in score units (inf: no prefilter possible).  Host code.
+double build_credits(const double *pairsum, int npair, double thr, uint16_t *out);
+void pair_sums(const double *letter_table, int m, double *out);      // [m][8] -> [ceil(m/2)][16]
 
 // Second phase of the candidate-then-verify combined scan: structure score of the windows
 // listed in cand_pos[0 .. min(*cand_count, cand_cap)) (hits of a letters-only pass, whose

@@ -50,6 +50,8 @@
 //   rnascan.py:422-423 combined hit <=> both tables hold (id, start, end)
 #include <float.h>
 #include <math.h>
+#include <cmath>
+#include <cstring>
 #include "pfmscan_internal.hpp"
 
 namespace pfmscan {
@@ -491,6 +493,232 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
 
         // tile boundary: publish the next tile's codes and this wave's queue length, ONE barrier
         const bool more = tb + 1 < ntile && tile0 + LET_TILE < n_pos;
+        if (more) cs.park(cbuf[(tb + 1) & 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) snap[tb & 1][wave] = q_n[wave];
+        __syncthreads();
+        if (tb + 2 < ntile && tile0 + 2 * (int64_t)LET_TILE < n_pos) cs.fetch(a.codes, tile0 + 2 * (int64_t)LET_TILE, n_pos);
+        int nq[NWAVE], total = 0, most = 0, before = 0;
+#pragma unroll
+        for (int k = 0; k < NWAVE; ++k) {
+            nq[k] = snap[tb & 1][k];
+            if (k < wave) before += nq[k];
+            total += nq[k];
+            most = most > nq[k] ? most : nq[k];
+        }
+        qn_ub = nq[wave];
+        if (most >= WQ_CAP / 2 || (!more && total > 0)) {          // uniform: every thread read the same snapshot
+            if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)total);
+            __syncthreads();
+            drain(s_base + (unsigned long long)before, nq[wave]);
+            qn_ub = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_letters_cred -- k_letters_pre with the INTEGER prefilter of the library kernel, keyed by stream position.
+// (PFMs up to width 16 over a 4-letter alphabet with a finite threshold)
+//
+// k_letters_pre spends its time on ceil(m/2) four-byte look-ups and as many fp32 adds per window, plus the index
+// arithmetic of each.  Here the two-letter table is turned around: ONE entry per letter pair holds that pair's
+// credit for EVERY pair row, two rows per dword (unsigned 16-bit fixed point, rounded so that a hit can never be
+// dropped: pfmscan_library_api.hip, build_credits):
+//     ctab[pair of the letters at positions q, q+1] = { (row0 | row1 << 16), (row2 | row3 << 16), ... }      NJ dwords
+// A lane owns W = 16 consecutive windows and reads ctab ONCE per position of its band (W + 4 NJ - 2 reads of 4 NJ
+// bytes, ~1.4 per window) instead of ceil(m/2) times per window.  Row 2j of position q belongs to window q - 4j,
+// row 2j+1 to window q - 4j - 2, so with the packs  P[w] = (credits of window w+2 | credits of window w) << 16
+//     P[w] = d0(w+2) + d1(w+6) + d2(w+10) + d3(w+14)          one v_add3_u32 (+ one add) per TWO windows' halves
+//     sum(w) = (P[w] >> 16) + (P[w-2] & 0xffff)               bit 15 set <=> the window may be a hit
+// (the threshold is folded into row 0).  Survivors are NOT re-scored in place (a wave pass per surviving window with one or
+// two live lanes was 45 % of the kernel at -m 6): their positions go to a wave-private LDS queue that lives across tiles,
+// and 64 at a time they get the exact score -- letters re-read from global memory (L2), sequential fp64 sum, float32
+// cast, strict compare -- one survivor per lane.  Hits: k_letters_pre's LDS hit queues, one returning atomic per flush.
+// ---------------------------------------------------------------------------
+struct CredTable {
+    uint32_t d[16][4];                                // [letter pair c0 | c1 << 2][row pair j]
+};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int NJ> struct CredEntry { typedef u32x4 type; };          // 3 or 4 row pairs: 16-byte entries
+template <> struct CredEntry<2> { typedef u32x2 type; };
+template <> struct CredEntry<1> { typedef uint32_t type; };
+
+template <int NJ>
+__global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const CredTable ct)
+{
+    constexpr int W = 16;                              // windows per lane = one round per tile
+    constexpr int LET_TILE = BLOCK * W;
+    constexpr int NPOS = W + 4 * NJ - 2;               // positions a lane looks up: q = 0 .. W + 4 NJ - 3
+    constexpr int NWD = (NPOS + 1 + 3) / 4;            // code dwords holding bytes 0 .. NPOS (the pair at q needs byte q + 1)
+    constexpr int ESH = NJ == 1 ? 2 : (NJ == 2 ? 3 : 4);   // log2 of the entry size in bytes
+    constexpr int NWAVE = BLOCK / 64;
+    typedef typename CredEntry<NJ>::type entry_t;
+    __shared__ __align__(16) double tbl[16 * 8];
+    __shared__ __align__(16) uint32_t ctab[16 << (ESH - 2)];
+    __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
+    __shared__ int64_t q_pos[NWAVE][WQ_CAP];
+    __shared__ float q_sc[NWAVE][WQ_CAP];
+    __shared__ int q_n[NWAVE], snap[2][NWAVE];
+    __shared__ unsigned long long s_base;
+    __shared__ int64_t sv_pos[NWAVE][128];             // survivors of the prefilter waiting for their exact score
+    const int m = a.m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_pos = a.n_pos;
+    const int ntile = a.tiles_per_block;
+    const int64_t first = (int64_t)blockIdx.x * ntile * LET_TILE;
+    if (first >= n_pos) return;                        // whole workgroup
+
+    CodeStage<LET_TILE> cs;
+    cs.fetch(a.codes, first, n_pos);
+    // rows m .. 15 are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
+    for (int i = threadIdx.x; i < 16 * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
+    for (int i = threadIdx.x; i < (16 << (ESH - 2)); i += BLOCK) ctab[i] = ct.d[i >> (ESH - 2)][i & ((1 << (ESH - 2)) - 1)];
+    if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
+    cs.park(cbuf[0]);
+    if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
+    __syncthreads();
+
+    const char *cbytes = (const char *)ctab;
+    const int shard = blockIdx.x & (a.hit_shards - 1);
+    const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.capacity;
+    unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
+    int64_t *my_pos = q_pos[wave];
+    float *my_sc = q_sc[wave];
+
+    auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
+        if ((int64_t)slot < a.capacity) {             // capacity is per shard
+            a.hit_pos[shard_off + slot] = pos + a.pos_offset;
+            if (a.hit_seq) a.hit_seq[shard_off + slot] = sc;
+            if (a.hit_struct) a.hit_struct[shard_off + slot] = (double)sc;
+        }
+    };
+    auto drain = [&](unsigned long long base, int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < n; i += 64) store_hit(base + i, my_pos[i], my_sc[i]);
+        if (lane == 0) q_n[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto wave_flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = __builtin_amdgcn_readfirstlane(q_n[wave]);
+        if (n == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned long long)n);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        drain(((unsigned long long)hi << 32) | lo, n);
+    };
+
+    int qn_ub = 0;                                     // wave-uniform upper bound of q_n[wave]
+    int sv_n = 0;                                      // wave-uniform length of the survivor queue (< 64 between windows)
+    int64_t *my_sv = sv_pos[wave];
+    // exact score of survivors [at, at + cnt) of this wave's queue, one per lane (_pwm.c:34-68)
+    auto exact_batch = [&](int at, int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (qn_ub + cnt > WQ_CAP) {                    // room for a hit per lane in the hit queue
+            wave_flush();
+            qn_ub = 0;
+        }
+        qn_ub += cnt;
+        if (lane < cnt) {
+            const int64_t p = my_sv[at + lane];
+            const int64_t al = p & ~(int64_t)3;
+            uint32_t raw[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) raw[k] = load_codes4(a.codes, al + 4 * k, n_pos);
+            double sc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t cw = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int j = 4 * k + b;
+                    if (j < 4 * NJ) sc += tbl[j * 8 + ((cw >> (8 * b)) & 7u)];      // rows m .. 4 NJ - 1 are zeros
+                }
+            }
+            const float f = (float)sc;
+            if ((double)f > a.thr_seq) {
+                const int slot = atomicAdd(&q_n[wave], 1);     // LDS
+                my_pos[slot] = p;
+                my_sc[slot] = f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int tb = 0; tb < ntile; ++tb) {
+        const int64_t tile0 = first + (int64_t)tb * LET_TILE;
+        if (tile0 >= n_pos) break;                     // uniform; the previous tile flushed (it was the last)
+        const uint8_t *cb = cbuf[tb & 1];
+        const int off0 = threadIdx.x * W;
+        uint32_t w[NWD + 1];
+#pragma unroll
+        for (int d = 0; d < NWD + 1; ++d) w[d] = *reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d);   // inside the halo
+        // z[d] byte k = entry offset of the pair at byte 4d+k: (c[4d+k] | c[4d+k+1] << 2) << ESH  (<= 0xF0)
+        uint32_t z[NWD];
+#pragma unroll
+        for (int d = 0; d < NWD; ++d) {
+            const uint32_t x0 = (w[d] & 0x03030303u) << ESH, x1 = (w[d + 1] & 0x03030303u) << ESH;
+            z[d] = x0 | (__builtin_amdgcn_alignbit(x1, x0, 8) << 2);
+        }
+        // one look-up per position; P[w + 2] in the text above is pk[w + 2] here (w = -2 .. W-1)
+        uint32_t pk[W + 2];
+#pragma unroll
+        for (int i = 0; i < W + 2; ++i) pk[i] = 0u;
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q) {
+            const uint32_t off = (z[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+            const entry_t e = *reinterpret_cast<const entry_t *>(cbytes + off);
+            uint32_t dj[4] = {0u, 0u, 0u, 0u};
+            if constexpr (NJ == 1) {
+                dj[0] = e;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) dj[j] = e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int wi = q - 2 - 4 * j;          // pack of the hi window w = q - 4j - 2
+                if (wi >= -2 && wi <= W - 1) pk[wi + 2] += dj[j];
+            }
+        }
+        uint32_t sum[W];
+        uint32_t any = 0;
+#pragma unroll
+        for (int v = 0; v < W; ++v) {
+            sum[v] = (pk[v + 2] >> 16) + (pk[v] & 0xFFFFu);
+            any |= sum[v];
+        }
+        // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes and score NaN later)
+        if (__builtin_amdgcn_ballot_w64((any & 0x8000u) != 0)) {
+#pragma unroll
+            for (int v = 0; v < W; ++v) {
+                const bool sv = (sum[v] & 0x8000u) != 0;
+                const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
+                if (sb) {                               // wave-uniform
+                    if (sv) my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = tile0 + off0 + v;
+                    sv_n += __popcll(sb);
+                    if (sv_n >= 64) {                   // the top 64 get their exact score, the rest stays
+                        exact_batch(sv_n - 64, 64);
+                        sv_n -= 64;
+                    }
+                }
+            }
+        }
+
+        // tile boundary: publish the next tile's codes and this wave's queue length, ONE barrier
+        const bool more = tb + 1 < ntile && tile0 + LET_TILE < n_pos;
+        if (!more && sv_n > 0) {                       // last tile of the workgroup: the waiting survivors, then the final flush
+            exact_batch(0, sv_n);
+            sv_n = 0;
+        }
         if (more) cs.park(cbuf[(tb + 1) & 1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1016,6 +1244,28 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
     // 8 windows per thread (hits: 0.39 vs 0.49 ms on C2 w=12; scores, with the LDS transpose that keeps
     // the stores 1 KiB contiguous: 0.39 vs 0.42 ms on C2 w=8; without the transpose 0.56 ms)
+    if (a.hits && a.pair_table && a.h_pairsum && a.m <= 16 && t.credits && std::isfinite(a.thr_seq) && NDW == 5) {
+        // integer position-keyed prefilter (k_letters_cred): tile = 4096 windows as below
+        const int npair = (a.m + 1) / 2, nj = (npair + 1) / 2;
+        uint16_t cr[8 * 16];
+        const double slack = build_credits(a.h_pairsum, npair, a.thr_seq, cr);
+        if (std::isfinite(slack)) {                   // +inf / NaN two-letter sums: the fp32 prefilter below handles them
+            CredTable ct;
+            std::memset(&ct, 0, sizeof(ct));
+            for (int i = 0; i < 16; ++i)
+                for (int tr = 0; tr < npair; ++tr) ct.d[i][tr >> 1] |= (uint32_t)cr[tr * 16 + i] << (16 * (tr & 1));
+            ScanArgs b = a;
+            const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
+            b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+            if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
+            const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
+            if (nj == 1) hipLaunchKernelGGL((k_letters_cred<1>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+            else if (nj == 2) hipLaunchKernelGGL((k_letters_cred<2>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+            else if (nj == 3) hipLaunchKernelGGL((k_letters_cred<3>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+            else hipLaunchKernelGGL((k_letters_cred<4>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+            return hipGetLastError();
+        }
+    }
     if (a.hits && a.pair_table) {
         // >= 2048 workgroups when the stream allows, at most 32 tiles per workgroup
         ScanArgs b = a;

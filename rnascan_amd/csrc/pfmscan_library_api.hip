@@ -37,7 +37,9 @@ struct LibPass {
 
 // Credits of ONE motif at threshold thr (see the header comment): pairsum [npair][16], out [npair][16].
 // Returns the one-sided slack of the prefilter in score units (0 when no window can pass, inf without prefilter).
-double build_credits(const double *pairsum, int npair, double thr, uint16_t *out)
+}  // namespace
+
+double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint16_t *out)
 {
     std::fill(out, out + (size_t)npair * 16, (uint16_t)0);
     if (thr == INFINITY) return 0.0;                      // nothing exceeds +inf: all credits 0, bit 15 never set
@@ -88,7 +90,7 @@ double build_credits(const double *pairsum, int npair, double thr, uint16_t *out
 
 // exact two-letter sums of one letter table [m][8] -> [npair][16], index c0 | c1 << 2 (an odd width's last pair
 // ignores its second letter)
-void pair_sums(const double *T, int m, double *out)
+void pfmscan::pair_sums(const double *T, int m, double *out)
 {
     const int npair = (m + 1) / 2;
     for (int t = 0; t < npair; ++t)
@@ -96,8 +98,6 @@ void pair_sums(const double *T, int m, double *out)
             for (int c1 = 0; c1 < 4; ++c1)
                 out[t * 16 + (c0 | c1 << 2)] = T[(2 * t) * 8 + c0] + (2 * t + 1 < m ? T[(2 * t + 1) * 8 + c1] : 0.0);
 }
-
-}  // namespace
 
 struct pfmscan_library {
     pfmscan_ctx *ctx = nullptr;

@@ -480,3 +480,33 @@ def test_integration_md_pwm_stub_runs_verbatim(tmp_path, golden):
         have = np.array(bits, dtype=np.uint32)
         nan = np.isnan(want.view(np.float32))
         assert np.array_equal(np.isnan(have.view(np.float32)), nan) and np.array_equal(have[~nan], want[~nan])
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 15, 16])
+def test_integer_prefilter_kernel_every_width(ctx, oracle, monkeypatch, m):
+    """k_letters_cred (position-keyed integer credits, PFMs up to width 16) against the oracle and against the fp32
+    prefilter kernel (PFMSCAN_CREDITS=0), thresholds from 'nothing passes' to 'everything passes', ON scores included,
+    -inf cells, foreign letters, several tiles per workgroup"""
+    from rnascan_amd import _lib
+    rng = np.random.default_rng(900 + m)
+    T = rand_table(rng, m, 4, inf_frac=0.1 if m % 3 == 0 else 0.0)
+    s = rand_stream(rng, 30, 0, 2500, foreign=0.004)
+    want_seq = oracle.stream_seq(s.codes, T)
+    fin = np.sort(want_seq[np.isfinite(want_seq)].astype(np.float64))
+    thrs = [1e30, float(fin[-1]), float(fin[int(0.999 * (fin.size - 1))]), float(fin[int(0.97 * (fin.size - 1))]),
+            float(np.nextafter(np.float32(fin[int(0.97 * (fin.size - 1))]), np.float32(-np.inf))), 6.0, 0.0, float(fin[0]), -1e30]
+    monkeypatch.setenv("PFMSCAN_TILES_PER_BLOCK", "3")
+    cred = _lib.Context(0)
+    monkeypatch.setenv("PFMSCAN_CREDITS", "0")
+    plain = _lib.Context(0)
+    m1, m0 = cred.motif(letter_table=T), plain.motif(letter_table=T)
+    for thr in thrs:
+        want_pos = oracle.stream_hits(want_seq, None, thr, thr)
+        for c, mo in ((cred, m1), (plain, m0)):
+            pos, sq, _ = c.hits_host(mo, s.codes, thr_seq=thr)
+            assert np.array_equal(pos, want_pos), (m, thr)
+            assert_f32_bits_equal(sq, want_seq[want_pos])
+    m1.close()
+    m0.close()
+    cred.close()
+    plain.close()
