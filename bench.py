@@ -435,6 +435,10 @@ def main():
                 "prefilter_slack_score_units": info["max_prefilter_eps"],
             }
         if world == 1 and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
+            # every logical CPU this process may run on (north_star: "all host cores"); libgomp's own default stops at
+            # the physical core count on this box (128 of 256), so the thread count is set before the oracle loads
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+            os.environ.setdefault("OMP_NUM_THREADS", str(usable))
             from oracle import oracle
             oracle.build()
             stride = args.length + 1
@@ -452,14 +456,13 @@ def main():
             nrec = int(max(probe, min(args.records, probe * args.cpu_seconds / max(dt, 1e-6))))
             dt, ref_seq, ref_st = cpu_run(nrec)
             nwin = nrec * (args.length - args.width + 1)
-            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             result["cpu_baseline"] = {
                 "value": nwin / dt, "unit": "windows/s", "cores": oracle.num_threads(), "kind": "port",
                 "sample": "first %d of %d records (%d windows), oracle/pfm_oracle.c stream_seq + stream_struct_f32, "
                           "OpenMP over positions, %.2f s" % (nrec, args.records, nwin, dt),
                 "host_cpus": os.cpu_count(), "usable_cpus": usable,
-                "cores_note": "OpenMP uses every CPU of this process's affinity mask (%d of the host's %d logical CPUs are "
-                              "usable by it); more threads than that would only time-share them" % (usable, os.cpu_count()),
+                "cores_note": "OMP_NUM_THREADS = the CPUs of this process's affinity mask (%d of the host's %d logical CPUs)"
+                              % (usable, os.cpu_count()),
             }
             got_seq = out_seq[: nrec * stride].cpu().numpy()
             got_st = out_st[: nrec * stride].cpu().numpy()
@@ -479,7 +482,7 @@ def main():
                 # pandas iloc + np.dot + nan_to_num, multiprocessing.Pool over records) on a
                 # small sample of the same records, scaled linearly in records (independent)
                 from oracle import ref_structured
-                cores = min(usable, 128)
+                cores = usable
                 n_seq, n_st = cores * 4, cores
                 lut = np.array(list("ACGU") + ["N"] * 4)
                 seqs, profs = [], []
