@@ -137,6 +137,9 @@ def main():
         args.minscore_seq = args.minscore_struct = args.minscore
     if args.from_host and args.mode == "scores":
         args.mode = "hits"
+    # the cpu_baseline leg uses every logical CPU this process may run on (north_star: "all host cores").  libgomp reads
+    # OMP_NUM_THREADS when it is LOADED (torch loads it), and its own default stops at 128 of this box's 256 CPUs.
+    os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()))
 
     import torch
     from rnascan_amd import _lib
@@ -435,10 +438,7 @@ def main():
                 "prefilter_slack_score_units": info["max_prefilter_eps"],
             }
         if world == 1 and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
-            # every logical CPU this process may run on (north_star: "all host cores"); libgomp's own default stops at
-            # the physical core count on this box (128 of 256), so the thread count is set before the oracle loads
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-            os.environ.setdefault("OMP_NUM_THREADS", str(usable))
             from oracle import oracle
             oracle.build()
             stride = args.length + 1
