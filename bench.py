@@ -309,7 +309,9 @@ def main():
     rank_parity = None
     if world > 1 and args.mode == "scores" and not seq_only and not args.no_cpu_baseline:
         from oracle import oracle
-        oracle.build()
+        if rank == 0:
+            oracle.build()                   # one rank compiles (when stale at all), the others load the finished library
+        barrier()
         stride = args.length + 1
         nrec = min(args.records, 8)
         c = codes[: nrec * stride].cpu().numpy()

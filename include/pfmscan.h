@@ -194,6 +194,10 @@ int pfmscan_hits_pipeline_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
  * forms above are exactly stage + *_staged. */
 int pfmscan_stage(pfmscan_ctx *ctx, const uint8_t *codes, const void *profile,
                   int profile_dtype, int64_t n_pos);
+/* positions of the stream staged in `ctx` (what pfmscan_scan_staged writes per output array), -1 when nothing is
+ * staged.  pfmscan_scan_host / pfmscan_hits_host / pfmscan_pwm_calculate / the pipeline restage or unstage: size the
+ * out arrays from THIS, not from what was passed to an earlier pfmscan_stage. */
+int64_t pfmscan_staged_positions(const pfmscan_ctx *ctx);
 int pfmscan_scan_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                         float *out_seq, double *out_struct);
 int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,

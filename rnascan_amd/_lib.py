@@ -32,7 +32,7 @@ SYMBOLS = [
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
-    "pfmscan_hits_pipeline_host",
+    "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
     L.pfmscan_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_stage.argtypes = [vp, vp, vp, i32, i64]
     L.pfmscan_scan_staged.argtypes = [vp, vp, vp, vp]
+    L.pfmscan_staged_positions.argtypes = [vp]
     L.pfmscan_hits_staged.argtypes = [vp, vp, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_time_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, i32, i32, ctypes.POINTER(dbl)]
     L.pfmscan_library_create.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(vp)]
@@ -112,8 +113,10 @@ def load():
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     for name in SYMBOLS:          # every other entry point returns a status
-        if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy"):
+        if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
+                        "pfmscan_staged_positions"):
             getattr(L, name).restype = i32
+    L.pfmscan_staged_positions.restype = i64
     if L.pfmscan_abi_version() != ABI_VERSION:
         raise ImportError("libpfmscan ABI %d, bindings expect %d" % (L.pfmscan_abi_version(), ABI_VERSION))
     _lib = L
@@ -304,7 +307,7 @@ class Context(object):
         return self.scratch_gen
 
     def scan_staged(self, motif, want_seq=True, want_struct=True):
-        n = self._staged_n
+        n = int(self._L.pfmscan_staged_positions(self._h))      # the library's own count sizes the outputs, not a Python copy of it
         if n < 0:
             raise ValueError("no stream staged (call stage first)")
         out_seq = np.empty(n, dtype=np.float32) if (want_seq and motif.has_letters) else None
@@ -313,7 +316,7 @@ class Context(object):
         return out_seq, out_struct
 
     def hits_staged(self, motif, thr_seq=-np.inf, thr_struct=-np.inf, capacity=None):
-        n = self._staged_n
+        n = int(self._L.pfmscan_staged_positions(self._h))
         if n < 0:
             raise ValueError("no stream staged (call stage first)")
         cap = int(capacity) if capacity is not None else max(1024, n // 64)
@@ -338,7 +341,7 @@ class Context(object):
     def library_hits_staged(self, lib, thr_seq, thr_struct=None, capacity=None):
         """hits of every motif of ``lib`` over the staged stream, sorted by (position, motif index)
         -> (pos int64[k], motif int32[k], seq float32[k], struct float64[k] | None)"""
-        n = self._staged_n
+        n = int(self._L.pfmscan_staged_positions(self._h))
         if n < 0:
             raise ValueError("no stream staged (call stage first)")
         ts, tt = lib.thresholds(thr_seq, thr_struct)

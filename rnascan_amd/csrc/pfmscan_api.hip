@@ -539,6 +539,8 @@ static int check_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo)
     return PFMSCAN_OK;
 }
 
+int64_t pfmscan_staged_positions(const pfmscan_ctx *ctx) { return ctx ? ctx->staged_n : -1; }
+
 int pfmscan_scan_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, float *out_seq, double *out_struct)
 {
     int rc = check_staged(ctx, mo);

@@ -510,3 +510,24 @@ def test_integer_prefilter_kernel_every_width(ctx, oracle, monkeypatch, m):
     m0.close()
     cred.close()
     plain.close()
+
+
+def test_staged_length_follows_the_library_not_a_stale_copy(ctx, oracle):
+    """scan_host / hits_host / pwm_calculate restage inside the library: a following scan_staged sizes its outputs from
+    pfmscan_staged_positions, never from the length of an earlier stage() (that was a host heap overflow)"""
+    rng = np.random.default_rng(17)
+    small = rand_stream(rng, 3, 50, 80)
+    large = rand_stream(rng, 40, 200, 900)
+    T = rand_table(rng, 8)
+    motif = ctx.motif(letter_table=T)
+    ctx.stage(small.codes)
+    ctx.scan_host(motif, large.codes)                    # restages the longer stream
+    sq, _ = ctx.scan_staged(motif)
+    assert sq.shape[0] == large.n_pos
+    assert_f32_bits_equal(sq, oracle.stream_seq(large.codes, T))
+    ctx.pwm_calculate("ACGUACGUACGUACGU", np.zeros((8, 4)))     # restages 16 positions
+    assert ctx.scan_staged(motif)[0].shape[0] == 16
+    ctx.hits_pipeline_host(motif, large.codes, None, 2.0, -np.inf, 4096)      # leaves nothing staged
+    with pytest.raises(ValueError):
+        ctx.scan_staged(motif)
+    motif.close()
