@@ -249,3 +249,83 @@ def test_library_hits_dev_unordered_and_overflow(ctx, oracle):
         else:
             assert k > cap                                        # incomplete: the count says so
     lib.close()
+
+
+def test_library_on_tiny_and_empty_streams(ctx, oracle):
+    """no window fits / nothing staged / one window: the persistent kernel must leave cleanly"""
+    rng = np.random.default_rng(2)
+    T, P = make_library(rng, 10, 12)
+    lib = ctx.library(T, P)
+    from rnascan_amd import pack
+    for lengths in ([], [0], [3, 0, 11], [12], [5, 12, 13]):
+        codes = [rng.integers(0, 4, size=L).astype(np.uint8) for L in lengths]
+        profs = [rng.dirichlet(np.full(7, 0.3), size=L).astype(np.float32) if L else np.zeros((0, 7), np.float32) for L in lengths]
+        if not lengths:                                           # an empty stream has no hits (and is no error)
+            got = ctx.library_hits_host(lib, np.zeros(0, np.uint8), np.zeros((0, 7), np.float32), -50.0, -1e30)
+            assert len(got[0]) == 0
+            continue
+        s = pack.pack(codes, profs)
+        got = ctx.library_hits_host(lib, s.codes, s.profile, -50.0, -1e30)
+        want = oracle_library_hits(oracle, s, T, P, np.full(10, -50.0), np.full(10, -1e30))
+        assert len(got[0]) == len(want[0]) == 10 * sum(max(L - 11, 0) for L in lengths)
+        check(got, want, True)
+    lib.close()
+
+
+def test_sequence_library_beyond_two_to_the_31_positions(ctx, oracle):
+    """a stream longer than 2^31 positions goes through several launches (32-bit positions inside a launch, pos_base
+    between them): the hits of the last 3 M positions -- across the 2^31 border -- equal the oracle's on that slice, and
+    a window planted at the very end is found at its 64-bit position"""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 30e9:
+        pytest.skip("needs 30 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    n_pos = (1 << 31) + 1500000
+    rng = np.random.default_rng(6)
+    m, n = 12, 24
+    T, _ = make_library(rng, n, m, struct=False)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    codes = torch.randint(0, 4, (n_pos,), dtype=torch.uint8, device=dev, generator=g)
+    codes[3000::3001] = 7                                         # separators: records of 3000
+    best = np.argmax(T[5, :, :4], axis=1).astype(np.uint8)        # motif 5's best window, planted at the very end
+    codes[n_pos - m - 1:n_pos - 1] = torch.from_numpy(best).to(dev)
+    codes[n_pos - 1] = 7
+    lib = ctx.library(T, None)
+    lo = n_pos - 3000000
+    tail = codes[lo:].cpu().numpy()
+    ts = np.empty(n)
+    for j in range(n):                                            # ~1e-4 of the windows per motif
+        sq = oracle.stream_seq(tail, T[j]).astype(np.float64)
+        ts[j] = np.quantile(sq[np.isfinite(sq)], 1.0 - 1e-4)
+    cap = 1 << 24
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hm = torch.empty(cap, dtype=torch.int32, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    from rnascan_amd import _lib
+    ctx.library_hits_dev(lib, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, ts, None, cap, hp.data_ptr(), hm.data_ptr(),
+                         hs.data_ptr(), None, cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    assert 0 < k <= cap
+    sel = torch.nonzero(hp[:k] >= lo + m).flatten()              # windows wholly inside the slice
+    gp, gm, gs = hp[:k][sel].cpu().numpy(), hm[:k][sel].cpu().numpy(), hs[:k][sel].cpu().numpy()
+    order = np.lexsort((gm, gp))
+    gp, gm, gs = gp[order], gm[order], gs[order]
+    wp, wm, ws = [], [], []
+    for j in range(n):
+        sq = oracle.stream_seq(tail, T[j])
+        p = oracle.stream_hits(sq, None, ts[j], -np.inf)
+        p = p[p >= m]
+        wp.append(p + lo)
+        wm.append(np.full(p.size, j, np.int32))
+        ws.append(sq[p])
+    wp, wm, ws = np.concatenate(wp), np.concatenate(wm), np.concatenate(ws)
+    o2 = np.lexsort((wm, wp))
+    assert len(gp) == len(wp) > 1000 and (gp > (1 << 31)).any() and (gp < (1 << 31)).any()
+    assert np.array_equal(gp, wp[o2]) and np.array_equal(gm, wm[o2])
+    assert_f32_bits_equal(gs, ws[o2])
+    assert ((gp == n_pos - m - 1) & (gm == 5)).any()
+    lib.close()
