@@ -159,7 +159,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # PFMSCAN_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1): the RCCL process group, barrier, MAX reduction and
+    # object gather of the multi-GPU path with ONE rank -- the only way to run that code on a one-GPU box
+    if world > 1 or os.environ.get("PFMSCAN_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group("gloo")
@@ -307,7 +309,7 @@ def main():
 
     # ---- per-rank parity sample (multi-GPU runs): a few records of THIS rank's shard against the CPU oracle
     rank_parity = None
-    if world > 1 and args.mode == "scores" and not seq_only and not args.no_cpu_baseline:
+    if dist is not None and args.mode == "scores" and not seq_only and not args.no_cpu_baseline:
         from oracle import oracle
         if rank == 0:
             oracle.build()                   # one rank compiles (when stale at all), the others load the finished library
@@ -401,7 +403,7 @@ def main():
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
-        if world > 1:
+        if dist is not None:
             result["per_rank"] = {"kernel_ms": rank_ms, "parity_sample_ok": rank_ok,
                                   "note": "no 1 -> N curve is claimed by this line: value = all ranks' windows / max-over-ranks time"}
         if args.from_host:
@@ -439,7 +441,7 @@ def main():
                 "fp64_tflops_of_73_measured": None if cand is None else cand * args.width * 14 / (kernel_ms * 1e-3) / 1e12,
                 "prefilter_slack_score_units": info["max_prefilter_eps"],
             }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
+        if dist is None and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             from oracle import oracle
             oracle.build()
