@@ -1,0 +1,45 @@
+"""End-to-end CLI run at scale on the GPU box: R synthetic records x L nt as a FASTA + a packed profile store, through
+bin/rnascan's main() with the real engine; prints wall times per stage.  usage: python tools/cli_e2e.py [R] [L]"""
+import io, json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+from rnascan_amd import cli, store
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
+d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+rng = np.random.default_rng(0)
+t0 = time.time()
+fa = os.path.join(d, "seqs.fa")
+letters = np.frombuffer(b"ACGU", dtype=np.uint8)
+with open(fa, "wb") as f:
+    for i in range(R):
+        f.write(b">t%d transcript %d\n" % (i, i))
+        f.write(letters[rng.integers(0, 4, size=L)].tobytes() + b"\n")
+# packed store written directly (the converter's output format), float32
+sd = os.path.join(d, "packed")
+os.makedirs(sd)
+with open(os.path.join(sd, "profile.f32"), "wb") as f:
+    for lo in range(0, R, 1000):
+        n = min(1000, R - lo)
+        p = rng.dirichlet(np.full(7, 0.3), size=n * L).astype(np.float32).reshape(n, L, 7)
+        out = np.zeros((n, L + 1, 7), dtype=np.float32)
+        out[:, :L] = p
+        f.write(out.tobytes())
+json.dump({"format": 1, "dtype": "float32", "letters": list("BEHLMRT"), "ids": ["t%d" % i for i in range(R)],
+           "lengths": [L] * R, "n_pos": R * (L + 1), "file": "profile.f32", "separator_rows": "one zero row after each record"},
+          open(os.path.join(sd, "index.json"), "w"))
+print("inputs written in %.1f s (%s)" % (time.time() - t0, d), file=sys.stderr)
+for name, argv in (
+    ("seq only  -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", fa]),
+    ("struct only (store) -m 6", ["-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", sd]),
+    ("seq + struct (store) -m 0", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"),
+                                   "-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", "0",
+                                   "--profile-dtype", "float32", fa, sd]),
+):
+    out = io.StringIO()
+    t = time.time()
+    cli.main(argv, out=out)
+    dt = time.time() - t
+    print("%-28s %.2f s   %d rows   %.3g windows/s" % (name, dt, out.getvalue().count("\n") - 1, R * (L - 17) / dt))
