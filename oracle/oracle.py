@@ -173,6 +173,11 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads.argtypes = [ctypes.c_int]
+    lib().oracle_set_num_threads(int(n))
+
+
 # --------------------------------------------------------------------------
 # host arithmetic restated with plain loops
 # --------------------------------------------------------------------------

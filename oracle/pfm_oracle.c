@@ -223,6 +223,18 @@ int64_t oracle_stream_hits(const float *seq, const double *st, int64_t n,
     return k;
 }
 
+/* torch sets the process-wide OpenMP thread count to the physical core count when it is imported; the cpu_baseline leg
+ * of bench.py chooses its own count */
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP
