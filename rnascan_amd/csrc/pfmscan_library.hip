@@ -17,10 +17,10 @@
 //      window; its pair offsets are computed once per window and serve every octet, and because the octet count
 //      NG is a template parameter every table offset is an immediate of the ds_read.  Windows covering a
 //      foreign letter or separator are dropped here (their exact score is NaN, _pwm.c:61-66).
-//  queue: a flagged (window, motif octet) goes to the wave's private LDS queue (position, octet, flag bits, the
-//      window's letters as 2-bit codes): no atomics, waves never synchronise with each other.
-//  phase B (dense, once 64 items wait): one item per lane.  The exact score is the sequential fp64 sum of
-//      _pwm.c:34-68 from an LDS copy of the fp64 letter tables, cast to float32 and compared with the threshold --
+//  queue: a flagged (window, motif octet) goes to the wave's private LDS queue (position, octet, the accumulators' flag
+//      bytes as they are): no atomics, waves never synchronise with each other.
+//  phase B (dense, once 64 items wait): one item per lane.  The window's letters are read again (L2); the exact score
+//      is the sequential fp64 sum of _pwm.c:34-68 from an LDS copy of the fp64 letter tables, cast to float32 and compared with the threshold --
 //      only that decides.  A window that passes gets the exact structure score of rnascan.py:302-307
 //      (per-row nan_to_num, fp64): rows straight from global memory (the neighbours of a wave's windows are in
 //      L1/L2), the motif's PSSM from LDS.  Hits are compacted inside the wave; one returning atomic per batch on
@@ -140,23 +140,21 @@ __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const i
     return acc;
 }
 
-// flagged lanes of one octet -> the wave's queue.  mk = ballot of the flags (non-zero), qn = queue length.
-template <int NP>
+// flagged lanes of one octet -> the wave's queue.  mk = ballot of the flags (non-zero), qn = queue length.  An item is
+// three dwords: the window's position, and the flag BYTES of the 8 accumulators as they are (bit 7 of each byte = bit 15
+// of a credit sum): p0 = {x.lo, x.hi, y.lo, y.hi} = motifs 8g .. 8g+3, p1 = {z.lo, z.hi, w.lo, w.hi} = motifs 8g+4 .. 8g+7,
+// with the octet g in bits 0-5 of p1.  Decoding is phase B's business: here every instruction counts (phase A is bound by
+// VALU issue, and three octets out of four have a flagged lane somewhere in the wave).
 __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const unsigned long long mk, const int qn, const int g,
-                                         const uint32_t relpos, const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs,
-                                         uint32_t *q_cw)
+                                         const uint32_t relpos, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     if (flag) {
-        // flag bytes of the 8 accumulators: p0 = {x.lo, x.hi, y.lo, y.hi}, p1 = {z.lo, z.hi, w.lo, w.hi} (bit 7 of each
-        // byte = bit 15 of the credit sum); bits: byte b, bit 0 = motif 8g + b may be a hit, bit 1 = motif 8g + 4 + b
         const uint32_t p0 = __builtin_amdgcn_perm(acc.y, acc.x, 0x07050301u);
         const uint32_t p1 = __builtin_amdgcn_perm(acc.w, acc.z, 0x07050301u);
-        const uint32_t bits = ((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u);
         const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
         q_pos[slot] = relpos;
-        q_gs[slot] = bits | ((uint32_t)g << 2);           // g < 64 in bits 2-7 of byte 0
-#pragma unroll
-        for (int k = 0; k < NP / 8; ++k) q_cw[k * LIB_QCAP + slot] = cw[k];
+        q_p0[slot] = p0;
+        q_p1[slot] = (p1 & ~0x3Fu) | (uint32_t)g;          // v_bfi_b32
     }
 }
 
@@ -165,7 +163,7 @@ __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const
 // over after a drain.  A chunk brings ~1.3 items per octet at realistic thresholds, the queue takes >= 65.
 template <int K, int NG, int NP>
 __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
-                                               const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs, uint32_t *q_cw)
+                                               uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     int g_next = NG;
     int qs = __builtin_amdgcn_readfirstlane(qn);      // the queue length is wave-uniform: keep it (and the branches on it) scalar
@@ -183,7 +181,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
             g_next = fits ? NG : g;
             qs = fits ? qs + n : qs;
             asm volatile("" : "+s"(qs), "+s"(g_next));
-            if (fits) lib_push<NP>(acc, flag, mk, at, g, relpos, cw, q_pos, q_gs, q_cw);
+            if (fits) lib_push(acc, flag, mk, at, g, relpos, q_pos, q_p0, q_p1);
         }
     }
     qn = qs;
@@ -194,7 +192,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 // Needs qn < 64 on entry (an octet brings at most 64 items, the queue holds LIB_QCAP >= 127).
 template <int K, int NG, int NP>
 __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
-                                               const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs, uint32_t *q_cw)
+                                               uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     int qs = __builtin_amdgcn_readfirstlane(qn);
     g = __builtin_amdgcn_readfirstlane(g);
@@ -203,7 +201,7 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x80008000u) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
         if (mk) {
-            lib_push<NP>(acc, flag, mk, qs, g, relpos, cw, q_pos, q_gs, q_cw);
+            lib_push(acc, flag, mk, qs, g, relpos, q_pos, q_p0, q_p1);
             qs += __popcll(mk);
         }
         ++g;
@@ -215,18 +213,17 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
 // npair -> the K-row instantiation, over the pair counts of one width bucket (K = KLO .. NP)
 template <bool FAST, int K, int NG, int NP>
 __device__ __forceinline__ int lib_dispatch(const int npair, const int g, const lds_cptr (&rowp)[NP], int &qn,
-                                            const uint32_t relpos, const uint32_t (&cw)[NP / 8], uint32_t *q_pos, uint32_t *q_gs,
-                                            uint32_t *q_cw)
+                                            const uint32_t relpos, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     if constexpr (K >= NP) {
-        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
-        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, q_pos, q_p0, q_p1);
+        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, q_pos, q_p0, q_p1);
     } else {
         if (npair == K) {
-            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
-            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, q_pos, q_p0, q_p1);
+            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, q_pos, q_p0, q_p1);
         }
-        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, q_pos, q_p0, q_p1);
     }
 }
 
@@ -237,7 +234,6 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     constexpr int LIB_BLOCK = lib_block(NP);
     constexpr int LIB_WAVES = LIB_BLOCK / 64;
     constexpr int NMP = NG * 8;                     // motifs of the pass (padding motifs never flag)
-    constexpr int CW = NP / 8;                      // dwords of 2-bit codes per window (16 letters each)
     constexpr int NRAW = NP / 2 + 1;                // aligned code dwords a lane loads
     extern __shared__ __align__(16) unsigned char smem[];
     const int m = a.m, npair = a.npair;
@@ -252,9 +248,9 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     double *thr_s = pssm + (HAS_STRUCT ? (size_t)m * 8 * NMP : 0);
     double *thr_t = thr_s + NMP;
     uint32_t *qbase = reinterpret_cast<uint32_t *>(thr_t + NMP);
-    uint32_t *q_pos = qbase + (size_t)wave * LIB_QCAP * (2 + CW);
-    uint32_t *q_gs = q_pos + LIB_QCAP;
-    uint32_t *q_cw = q_gs + LIB_QCAP;               // [CW][LIB_QCAP]
+    uint32_t *q_pos = qbase + (size_t)wave * LIB_QCAP * 3;
+    uint32_t *q_p0 = q_pos + LIB_QCAP;
+    uint32_t *q_p1 = q_p0 + LIB_QCAP;
 
     for (int i = threadIdx.x; i < pair_bytes / 16; i += LIB_BLOCK)
         reinterpret_cast<u32x4 *>(pairs)[i] = reinterpret_cast<const u32x4 *>(a.pairs)[i];
@@ -284,12 +280,11 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const bool have = lane < cnt;
         const int idx = first + (have ? lane : 0);
         const uint32_t rel = q_pos[idx];
-        const uint32_t gsb = q_gs[idx];
-        uint32_t cw[CW];
-#pragma unroll
-        for (int k = 0; k < CW; ++k) cw[k] = q_cw[k * LIB_QCAP + idx];
-        uint32_t bits = have ? (gsb & 0x03030303u) : 0u;
-        const int g8 = (int)((gsb >> 2) & 63u) * 8;
+        const uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
+        // byte b, bit 0 = motif 8g + b flagged, bit 1 = motif 8g + 4 + b flagged
+        uint32_t bits = have ? (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u)) : 0u;
+        const uint32_t g = p1 & 0x3Fu;
+        const int g8 = (int)g * 8;
         const int64_t p = a.pos_base + (int64_t)rel;
         const bool act = bits != 0;
         const int q = act ? __builtin_ctz(bits) : 0;
@@ -301,13 +296,22 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (bits != 0) {
                 const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
-                q_gs[slot] = (gsb & ~0x03030303u) | bits;
-#pragma unroll
-                for (int k = 0; k < CW; ++k) q_cw[k * LIB_QCAP + slot] = cw[k];
+                q_p0[slot] = (bits & 0x01010101u) << 7;
+                q_p1[slot] = ((bits & 0x02020202u) << 6) | g;
             }
             requeued = __popcll(more);
         } else {
             requeued = 0;
+        }
+        // the window's letters again (L2: the wave read them a few chunks ago); it has no foreign letter, or it would not be here
+        uint32_t w[NP / 2];
+        {
+            const int64_t al = p & ~(int64_t)3;
+            uint32_t raw[NRAW];
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) raw[k] = (k < (m + 3) / 4 + 1) ? lib_codes4(a.codes, al + 4 * k, n_pos) : 0u;
+#pragma unroll
+            for (int k = 0; k < NP / 2; ++k) w[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
         }
         const int mo = g8 + (q >> 3) + 4 * (q & 1);   // pass-local motif
         // exact sequence score: sequential fp64 sum (_pwm.c:36-64), float32 cast (:65)
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 #pragma unroll
         for (int j = 0; j < NP * 2; ++j) {
             if (j < m) {
-                const uint32_t c = (cw[j >> 4] >> ((j & 15) * 2)) & 3u;
+                const uint32_t c = (w[j >> 2] >> ((j & 3) * 8)) & 3u;
                 sc += L[(j * 4) * NMP + c * NMP];
             }
         }
@@ -372,10 +376,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 for (int k = 0; k < NRAW; ++k) raw[k] = lib_codes4(a.codes, al + 4 * k, n_pos);
             }
             lds_cptr rowp[NP];
-            uint32_t cw[CW];
             uint32_t badbits = 0;
-#pragma unroll
-            for (int k = 0; k < CW; ++k) cw[k] = 0;
 #pragma unroll
             for (int k = 0; k < NP / 2; ++k) {
                 const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(lane & 3));
@@ -387,7 +388,6 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 const uint32_t y = x | (x >> 6);             // pair (b0,b1) in bits 0-3, pair (b2,b3) in bits 16-19
                 rowp[2 * k] = pairs_lds + (2 * k) * (NG * 256) + ((y & 0xFu) << 4);
                 rowp[2 * k + 1] = pairs_lds + (2 * k + 1) * (NG * 256) + (((y >> 16) & 0xFu) << 4);
-                cw[k >> 2] |= ((y & 0xFu) | ((y >> 12) & 0xF0u)) << (8 * (k & 3));
             }
             // windows starting past the span belong to the next launch / do not exist; a window that cannot score (dead)
             // takes its row 0 from the zero row: without the folded threshold bit 15 of its sums stays clear
@@ -396,14 +396,14 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (dead) rowp[0] = pairs_lds + pair_bytes;
 
             const uint32_t relpos = (uint32_t)(rel0 + lane);
-            int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+            int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, q_pos, q_p0, q_p1);
             for (;;) {
                 while (qn >= 64) {                           // the top 64 items; the rest stays (LIFO)
                     dense(qn - 64, 64);
                     qn += requeued - 64;
                 }
                 if (g >= NG) break;
-                g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_gs, q_cw);
+                g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, q_pos, q_p0, q_p1);
             }
         }
     }
@@ -419,7 +419,7 @@ size_t lib_motif_bytes(int m, int npair, bool has_struct)
     return (size_t)(npair + 1) * 32 + (size_t)m * 32 + (has_struct ? (size_t)m * 64 : 0) + 16;     // +1: the zero row
 }
 
-size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * (2 + np_bucket / 8) * 4; }
+size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * 3 * 4; }
 
 size_t lib_lds_bytes(int m, int npair, int nmp, bool has_struct, int np_bucket)
 {
