@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 2
+#define PFMSCAN_ABI_VERSION 3
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -259,6 +259,60 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib,
  * clear cannot be a hit; *slack = how far below the threshold a kept window's score may lie (score units). */
 int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq,
                                uint16_t *credits, double *slack);
+
+/* ---- host ingest and output (no device needed; no context: errors via pfmscan_last_error(NULL)) ---------------
+ * The two pieces of host work that dwarf the kernel at scale, in native code.
+ *
+ * FASTA bytes -> packed code stream.  Replaces SeqIO.parse + preprocess_seq + the per-record encode
+ * (rnascan/rnascan.py:170-174, :177-204): a record starts at a line whose first byte is '>', the header is that
+ * line without '>' and without trailing \r \n, the letters are every later line stripped of ASCII whitespace at
+ * both ends with embedded blanks removed; bytes before the first header are ignored.
+ *
+ * pfmscan_fasta_index: one pass over `buf`.  capacity == 0 (arrays may be NULL): only counts the records and
+ *   returns PFMSCAN_E_CAPACITY with *n_records set (PFMSCAN_OK when there are none).  Otherwise fills, per record,
+ *   hdr_off / hdr_len (header bytes), seq_off / seq_end (byte range of its sequence lines), n_letters.
+ * pfmscan_fasta_encode: records [lo, hi) -> codes[sum(n_letters + 1)]: lut256[byte] per letter, `separator`
+ *   after each record (stream layout above); offsets[i] = stream position of record lo + i.  n_threads <= 0:
+ *   as many as the host offers, at most 16. */
+int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t *hdr_off,
+                        int64_t *hdr_len, int64_t *seq_off, int64_t *seq_end, int64_t *n_letters,
+                        int64_t *n_records);
+int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64_t *seq_end,
+                         const int64_t *n_letters, int64_t lo, int64_t hi, const uint8_t *lut256,
+                         int separator, uint8_t *codes, int64_t *offsets, int n_threads);
+
+/* Hit columns -> the bytes `DataFrame.to_csv(sep='\t', index=False)` writes for them (rnascan/rnascan.py:555-567,
+ * Match_ID :329-332), without building the table: one descriptor per column, rows formatted in parallel.
+ *   CONST    data = bytes, width = their length (the same field in every row)
+ *   I64      data = int64 [n_rows]
+ *   F32/F64  data = float / double [n_rows]: shortest digits that round-trip in that precision, positional for
+ *            1e-4 <= |x| < 1e16 else d.ddde+XX (numpy's str / Python's repr); NaN = empty field, inf = "inf"
+ *   INDEXED  data = int64 index [n_rows], aux = int64 offsets [n_values + 1] into blob: row r holds
+ *            blob[offsets[i] .. offsets[i + 1]) for i = index[r]  (record ids, descriptions, motif ids; the
+ *            caller has applied csv quoting to the values)
+ *   FIXED    data = bytes [n_rows][width], trailing NULs dropped (numpy 'S' arrays)
+ *   WINDOW   data = int64 stream positions [n_rows], aux = the code stream, blob = 8 letters: the `width` letters
+ *            blob[code & 7] of the window at each position (the Sequence column)
+ * first_match_id >= 0 appends a last column counting up from it.  Every row ends in '\n'; no header line.
+ * PFMSCAN_E_CAPACITY: *n_bytes holds the size that suffices, nothing was written. */
+#define PFMSCAN_TSV_CONST   0
+#define PFMSCAN_TSV_I64     1
+#define PFMSCAN_TSV_F32     2
+#define PFMSCAN_TSV_F64     3
+#define PFMSCAN_TSV_INDEXED 4
+#define PFMSCAN_TSV_FIXED   5
+#define PFMSCAN_TSV_WINDOW  6
+typedef struct pfmscan_tsv_column {
+    int32_t kind;
+    int32_t reserved;
+    const void *data;
+    const void *aux;
+    const void *blob;
+    int64_t width;
+} pfmscan_tsv_column;
+int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_rows,
+                       int64_t first_match_id, char *out, int64_t capacity, int64_t *n_bytes,
+                       int n_threads);
 
 /* ---- measurement helper ------------------------------------------------------
  * Average device time in milliseconds of `iters` back-to-back pfmscan_scan_dev

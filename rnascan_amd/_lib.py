@@ -21,7 +21,7 @@ SEP = 7
 NCODE = 8
 NSTRUCT = 7
 MAX_M = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -33,7 +33,16 @@ SYMBOLS = [
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
+    "pfmscan_fasta_index", "pfmscan_fasta_encode", "pfmscan_tsv_format",
 ]
+TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW = range(7)
+
+
+class TsvColumn(ctypes.Structure):
+    """pfmscan_tsv_column of include/pfmscan.h"""
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("data", ctypes.c_void_p),
+                ("aux", ctypes.c_void_p), ("blob", ctypes.c_void_p), ("width", ctypes.c_int64)]
+
 
 
 class CapacityError(RuntimeError):
@@ -112,6 +121,9 @@ def load():
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
+    L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
+    L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), i32]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
                         "pfmscan_staged_positions"):
@@ -140,6 +152,77 @@ def _raise(L, ctx, rc, n_hits=None):
     if rc == E_CAPACITY:
         raise CapacityError(msg, n_hits)
     raise RuntimeError("libpfmscan: " + msg)
+
+
+# ---------------------------------------------------------------------------
+# host ingest / output (no device, no context)
+# ---------------------------------------------------------------------------
+def fasta_index(buf):
+    """uint8 array of FASTA bytes -> (hdr_off, hdr_len, seq_off, seq_end, n_letters), int64 [n_records] each."""
+    L = load()
+    buf = np.asarray(buf)
+    n = ctypes.c_int64(0)
+    rc = L.pfmscan_fasta_index(_ptr(buf), buf.size, 0, None, None, None, None, None, ctypes.byref(n))
+    if rc not in (OK, E_CAPACITY):
+        _raise(L, None, rc)
+    cols = [np.empty(n.value, dtype=np.int64) for _ in range(5)]
+    if n.value:
+        rc = L.pfmscan_fasta_index(_ptr(buf), buf.size, n.value, *[_ptr(c) for c in cols], ctypes.byref(n))
+        if rc != OK:
+            _raise(L, None, rc)
+    return tuple(cols)
+
+
+def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, threads=0):
+    """records [lo, hi) of an indexed FASTA buffer -> (codes uint8 [sum(L + 1)], offsets int64 [hi - lo])."""
+    L = load()
+    total = int(n_letters[lo:hi].sum()) + (hi - lo)
+    codes = np.empty(total, dtype=np.uint8)
+    offsets = np.empty(hi - lo, dtype=np.int64)
+    lut = np.ascontiguousarray(lut, dtype=np.uint8)
+    if lut.size != 256:
+        raise ValueError("lut must have 256 entries")
+    if hi > lo:
+        rc = L.pfmscan_fasta_encode(_ptr(buf), _ptr(seq_off), _ptr(seq_end), _ptr(n_letters), lo, hi, _ptr(lut), int(separator),
+                                    _ptr(codes), _ptr(offsets), int(threads))
+        if rc != OK:
+            _raise(L, None, rc)
+    return codes, offsets
+
+
+def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None):
+    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes; returns the rows as a bytearray."""
+    L = load()
+    keep, desc = [], (TsvColumn * len(columns))()
+    for i, (kind, data, aux, blob, width) in enumerate(columns):
+        ptrs = []
+        for obj in (data, aux, blob):
+            if obj is None:
+                ptrs.append(None)
+            elif isinstance(obj, (bytes, bytearray)):
+                arr = np.frombuffer(obj, dtype=np.uint8) if len(obj) else np.zeros(1, dtype=np.uint8)
+                keep.append(arr)
+                ptrs.append(arr.ctypes.data)
+            else:
+                arr = np.ascontiguousarray(obj)
+                keep.append(arr)
+                ptrs.append(arr.ctypes.data)
+        desc[i] = TsvColumn(int(kind), 0, ptrs[0], ptrs[1], ptrs[2], int(width))
+    cap = int(estimate) if estimate else max(1 << 16, n_rows * 96)
+    n = ctypes.c_int64(0)
+    while True:
+        out = bytearray(cap)
+        view = (ctypes.c_char * cap).from_buffer(out)
+        rc = L.pfmscan_tsv_format(desc, len(columns), int(n_rows), int(first_match_id), ctypes.addressof(view), cap, ctypes.byref(n),
+                                  int(threads))
+        del view
+        if rc == E_CAPACITY and n.value > cap:
+            cap = n.value
+            continue
+        if rc != OK:
+            _raise(L, None, rc)
+        del out[n.value:]
+        return out
 
 
 class Context(object):

@@ -120,6 +120,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
     and a ``sink`` the batches' tables go to ``sink(frame)`` one by one and None is returned."""
     rank, world, dist = dist_ctx
     ptype = np.dtype(args.profile_dtype).type
+    compact = sink is not None and world == 1            # streaming: hit columns go to the native writer as they are
     if isinstance(source, fasta.Record):
         df = scanner.scan_records(engine, [source], pssm, letters, args.minscore)
         df["Sequence_ID"] = "testseq"
@@ -133,7 +134,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         ids = list(range(len(ps.ids)))                 # batches of record indices: the mapped file is sliced, not copied
         df = shard.scan_sharded(ids, ps.lengths,
                                 lambda part: scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing,
-                                                                part[0] if part else 0, part[-1] + 1 if part else 0),
+                                                                part[0] if part else 0, part[-1] + 1 if part else 0, compact),
                                 rank, world, dist, sink=sink)
         fasta.eprint("Processed %d sequences" % len(ps.ids))
         return df
@@ -152,7 +153,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
             for sid, path in part:
                 file_letters, prof = fasta.read_profile(path)
                 named.append((sid, file_letters, prof))
-            return scanner.scan_profiles(engine, named, pssm, args.minscore, args.pairing, ptype)
+            return scanner.scan_profiles(engine, named, pssm, args.minscore, args.pairing, ptype, compact)
 
         df = shard.scan_sharded(files, weights, scan_files, rank, world, dist, sink=sink)
         fasta.eprint("Processed %d sequences" % len(files))
@@ -160,7 +161,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
     fasta.eprint("Scanning sequences ")
     recs = fasta.LazyFasta(source)                     # index only: a rank / a batch reads just its own records
     df = shard.scan_sharded(recs, recs.lengths,
-                            lambda part: scanner.scan_records(engine, part, pssm, letters, args.minscore),
+                            lambda part: scanner.scan_records(engine, part, pssm, letters, args.minscore, compact),
                             rank, world, dist, sink=sink)
     fasta.eprint("Processed %d sequences" % len(recs))
     return df
@@ -241,7 +242,9 @@ def main(argv=None, engine=None, out=None):
         writer[0] = table.TsvWriter(out, columns, match_id=True)
 
         def sink(frame):
-            if frame is not None and len(frame):
+            if isinstance(frame, dict):                  # compact hit columns (table.py)
+                writer[0].write_chunk(frame)
+            elif frame is not None and len(frame):
                 writer[0].write_chunk({c: frame[c].to_numpy() for c in writer[0].columns}, len(frame))
         return sink
 
@@ -254,6 +257,7 @@ def main(argv=None, engine=None, out=None):
         recs = fasta.LazyFasta(seq_source)
         fasta.eprint("Processed %d sequences" % len(recs))
         fasta.eprint("Scanning averaged secondary structures ")
+        ps = None
         if store.is_store(struct_source):
             ps = store.ProfileStore(struct_source)
             where = {}
@@ -284,9 +288,20 @@ def main(argv=None, engine=None, out=None):
             """one batch: the fused pass when its records and profiles pair one to one (same id, same length, same
             column order), else the reference's two tables + join for this batch (ids are unique, so the join of a
             batch is the batch of the join)"""
-            named = [t for r in part for t in load(r.id)]
-            df = scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore, args.pairing, ptype)
+            ids = list(part.ids) if hasattr(part, "ids") else [r.id for r in part]
+            named, prepacked = None, None
+            if ps is not None and ids:
+                # a packed store that holds these records in this order: its rows ARE the stream, no per-record copy
+                at = [where.get(rid, [-1])[0] for rid in ids]
+                if at[0] >= 0 and at == list(range(at[0], at[0] + len(at))):
+                    prepacked = (ids, ps.letters, ps.stream(at[0], at[0] + len(at)))
+            if prepacked is None:
+                named = [t for rid in ids for t in load(rid)]
+            df = scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore, args.pairing, ptype,
+                                       columns=streaming, prepacked=prepacked)
             if df is None:
+                if named is None:
+                    named = [t for rid in ids for t in load(rid)]
                 df = scanner.combine(scanner.scan_records(eng, part, seq_pssm, fasta.RNA, args.minscore),
                                      scanner.scan_profiles(eng, named, struct_pssm, args.minscore, args.pairing, ptype))
                 df = df[scanner.COMBINED_COLUMNS]

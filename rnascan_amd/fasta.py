@@ -9,6 +9,7 @@ import ast
 import bz2
 import glob
 import gzip
+import mmap
 import os
 import re
 import sys
@@ -63,85 +64,198 @@ def parse_sequences(fasta_files):
                 yield _record(header, chunks)
 
 
-class LazyFasta(object):
-    """A FASTA file as a sliceable sequence of Records that holds only an INDEX in memory: id, header, byte offset and
-    letter count per record, from one cheap pass over the bytes.  ``lazy[a:b]`` seeks to record a and parses b - a
-    records, so a rank of a sharded run (shard.scan_sharded) reads only its own share and a batch only its own
-    records -- the reference hands every record to a pool worker through one iterator (rnascan.py:379-395).
-    Compressed input (.gz / .bz2) cannot be seeked: its records are parsed once and kept."""
+class _Headers(object):
+    """the headers (or ids) of an indexed FASTA, decoded when asked for: a sequence-only scan needs the strings
+    of the records that have hits, not 10^5 of them up front"""
 
-    def __init__(self, fasta_files):
-        self.files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
-        self.ids, self.headers, self.lengths = [], [], []
-        self._where = []                       # (file index, byte offset) per record, or a parsed Record
-        for fi, path in enumerate(self.files):
-            if os.path.splitext(path)[1] in (".gz", ".bz2"):
-                for rec in parse_sequences(path):
-                    self._add(rec.id, rec.description, len(rec.seq), rec)
-                continue
-            with open(path, "rb") as fh:
-                off, cur, n = 0, None, 0
-                for line in fh:
-                    if line.startswith(b">"):
-                        if cur is not None:
-                            self._add(cur[0], cur[1], n, (fi, cur[2]))
-                        header = line[1:].rstrip(b"\r\n").decode("utf-8", "replace")
-                        words = header.split(None, 1)
-                        cur, n = (words[0] if words else "", header, off), 0
-                    elif cur is not None:
-                        n += len(line.strip().replace(b" ", b""))
-                    off += len(line)
-                if cur is not None:
-                    self._add(cur[0], cur[1], n, (fi, cur[2]))
-
-    def _add(self, rid, header, n, where):
-        self.ids.append(rid)
-        self.headers.append(header)
-        self.lengths.append(n)
-        self._where.append(where)
+    def __init__(self, owner, want_id):
+        self.owner = owner
+        self.want_id = want_id
+        self.cache = owner._header_cache
 
     def __len__(self):
-        return len(self.ids)
+        return len(self.owner)
 
-    def _read(self, lo, hi):
-        out = []
-        i = lo
-        while i < hi:
-            w = self._where[i]
-            if isinstance(w, Record):
-                out.append(w)
-                i += 1
-                continue
-            # the run of records lo.. that sit in the same file: one seek, parse until the run ends
-            fi, off = w
-            j = i
-            while j < hi and not isinstance(self._where[j], Record) and self._where[j][0] == fi:
-                j += 1
-            with open(self.files[fi], "rb") as fh:
-                fh.seek(off)
-                header, chunks, got = None, [], 0
-                for line in fh:
-                    if line.startswith(b">"):
-                        if header is not None:
-                            out.append(_record(header, chunks))
-                            got += 1
-                            if got == j - i:
-                                header = None
-                                break
-                        header, chunks = line[1:].rstrip(b"\r\n").decode("utf-8", "replace"), []
-                    elif header is not None:
-                        chunks.append(line.strip().decode("latin-1"))
-                if header is not None:
-                    out.append(_record(header, chunks))
-            i = j
-        return out
+    def _one(self, i):
+        got = self.cache.get(i)
+        if got is None:
+            header = self.owner._header(i)
+            words = header.split(None, 1)
+            got = self.cache[i] = (words[0] if words else "", header)
+        return got[0] if self.want_id else got[1]
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return [self._one(i) for i in range(*key.indices(len(self)))]
+        if key < 0:
+            key += len(self)
+        return self._one(key)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self._one(i)
+
+
+class _View(object):
+    """items [lo, hi) of a lazily decoded sequence, still lazy"""
+
+    def __init__(self, seq, lo, hi):
+        self.seq, self.lo, self.hi = seq, lo, hi
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self.seq[self.lo + i]
+
+    def __iter__(self):
+        for i in range(self.lo, self.hi):
+            yield self.seq[i]
+
+
+class FastaSlice(object):
+    """records [lo, hi) of a LazyFasta: a sequence of Records (parsed when iterated) that can also hand over its
+    letters already in stream form (``pack_rna``) without making a Python object per record."""
+
+    def __init__(self, parent, lo, hi):
+        self.parent, self.lo, self.hi = parent, lo, hi
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __iter__(self):
+        return iter(self.parent._read(self.lo, self.hi))
 
     def __getitem__(self, key):
         if isinstance(key, slice):
             lo, hi, step = key.indices(len(self))
             if step != 1:
                 raise ValueError("LazyFasta slices are contiguous")
-            return self._read(lo, max(lo, hi))
+            return FastaSlice(self.parent, self.lo + lo, self.lo + max(lo, hi))
+        if key < 0:
+            key += len(self)
+        return self.parent._read(self.lo + key, self.lo + key + 1)[0]
+
+    @property
+    def ids(self):
+        return _View(self.parent.ids, self.lo, self.hi)
+
+    @property
+    def descriptions(self):
+        return _View(self.parent.headers, self.lo, self.hi)
+
+    def pack_rna(self):
+        """(codes uint8 with one separator after every record, offsets, lengths) of the slice, the letters mapped
+        as preprocess_seq + pack.encode_rna map them (rnascan.py:186-197, _pwm.c:41-63: case-insensitive, T = U,
+        everything else foreign) -- by pfmscan_fasta_encode; None when a record does not sit in a plain file."""
+        return self.parent._pack(self.lo, self.hi, pack._RNA_LUT)
+
+
+class LazyFasta(object):
+    """A FASTA file as a sliceable sequence of Records that holds only an INDEX in memory: header location, byte range
+    and letter count per record, from one native pass over the mapped bytes (``pfmscan_fasta_index``).  ``lazy[a:b]``
+    is a FastaSlice: a rank of a sharded run (shard.scan_sharded) reads only its own share and a batch only its own
+    records -- the reference hands every record to a pool worker through one iterator (rnascan.py:379-395).
+    Compressed input (.gz / .bz2) cannot be mapped: its records are parsed once and kept."""
+
+    def __init__(self, fasta_files):
+        from . import _lib
+        self.files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
+        self._header_cache = {}
+        self._maps = []                        # per file: the mmap object (bytes slices for the headers)
+        self._bufs = []                        # per file: uint8 view of the mapped bytes, or None (compressed)
+        self._index = []                       # per file: (hdr_off, hdr_len, seq_off, seq_end, n_letters)
+        self._parsed = {}                      # global record index -> Record (compressed files)
+        file_of, local_of, lengths = [], [], []
+        for fi, path in enumerate(self.files):
+            if os.path.splitext(path)[1] in (".gz", ".bz2"):
+                self._maps.append(None)
+                self._bufs.append(None)
+                self._index.append(None)
+                base = sum(len(x) for x in lengths)
+                recs = list(parse_sequences(path))
+                for k, rec in enumerate(recs):
+                    self._parsed[base + k] = rec
+                file_of.append(np.full(len(recs), fi, dtype=np.int64))
+                local_of.append(np.arange(len(recs), dtype=np.int64))
+                lengths.append(np.array([len(r.seq) for r in recs], dtype=np.int64))
+                continue
+            if os.path.getsize(path):
+                with open(path, "rb") as fh:
+                    mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                buf = np.frombuffer(mm, dtype=np.uint8)
+            else:
+                mm, buf = b"", np.zeros(0, dtype=np.uint8)
+            idx = _lib.fasta_index(buf)
+            self._maps.append(mm)
+            self._bufs.append(buf)
+            self._index.append(idx)
+            file_of.append(np.full(idx[0].size, fi, dtype=np.int64))
+            local_of.append(np.arange(idx[0].size, dtype=np.int64))
+            lengths.append(idx[4])
+        self._file_of = np.concatenate(file_of) if file_of else np.zeros(0, dtype=np.int64)
+        self._local_of = np.concatenate(local_of) if local_of else np.zeros(0, dtype=np.int64)
+        self.lengths = (np.concatenate(lengths) if lengths else np.zeros(0, dtype=np.int64)).tolist()
+        self.ids = _Headers(self, True)
+        self.headers = _Headers(self, False)
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def _header(self, i):
+        rec = self._parsed.get(i)
+        if rec is not None:
+            return rec.description
+        fi, k = int(self._file_of[i]), int(self._local_of[i])
+        off, n = int(self._index[fi][0][k]), int(self._index[fi][1][k])
+        return self._maps[fi][off:off + n].decode("utf-8", "replace")
+
+    def _read(self, lo, hi):
+        out = []
+        for i in range(lo, hi):
+            rec = self._parsed.get(i)
+            if rec is None:
+                fi, k = int(self._file_of[i]), int(self._local_of[i])
+                idx = self._index[fi]
+                lines = self._maps[fi][int(idx[2][k]):int(idx[3][k])].split(b"\n")
+                rec = _record(self._header(i), [ln.strip().decode("latin-1") for ln in lines])
+            out.append(rec)
+        return out
+
+    def _pack(self, lo, hi, lut):
+        from . import _lib
+        if hi <= lo:
+            return np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        if self._parsed and any(i in self._parsed for i in range(lo, hi)):
+            return None
+        codes, offsets, base, i = [], [], 0, lo
+        while i < hi:                          # one native call per run of records that sit in the same file
+            fi = int(self._file_of[i])
+            j = i
+            while j < hi and int(self._file_of[j]) == fi:
+                j += 1
+            idx = self._index[fi]
+            a, b = int(self._local_of[i]), int(self._local_of[j - 1]) + 1
+            c, o = _lib.fasta_encode(self._bufs[fi], idx[2], idx[3], idx[4], a, b, lut, pack.SEP)
+            codes.append(c)
+            offsets.append(o + base)
+            base += c.size
+            i = j
+        lengths = np.asarray(self.lengths[lo:hi], dtype=np.int64)
+        if len(codes) == 1:
+            return codes[0], offsets[0], lengths
+        return np.concatenate(codes), np.concatenate(offsets), lengths
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            lo, hi, step = key.indices(len(self))
+            if step != 1:
+                raise ValueError("LazyFasta slices are contiguous")
+            return FastaSlice(self, lo, max(lo, hi))
         if key < 0:
             key += len(self)
         return self._read(key, key + 1)[0]

@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pandas as pd
 
-from . import _lib, fasta, pack
+from . import _lib, fasta, pack, table
 from .pssm import PSSM
 
 SEQ_COLUMNS = ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds"]
@@ -135,34 +135,96 @@ def _select(engine, stream, m, letter_table, struct_pssm, thr_seq, thr_struct):
 # ---------------------------------------------------------------------------
 # sequence / letter-string scans
 # ---------------------------------------------------------------------------
-def scan_records(engine, records, pssm, letters, minscore):
+class _RnaBatch(object):
+    """A batch of nucleotide records in stream form: the codes (one separator after each record), and where the
+    strings of a record are found when a hit needs them.  From a fasta.FastaSlice the letters are mapped and packed
+    natively from the mapped file (pfmscan_fasta_encode); from Records by preprocess_seq (rnascan.py:186-197) +
+    pack.encode_rna.  Either way a hit's ``Sequence`` is read back from the codes: a hit window holds the four
+    nucleotides only (a foreign letter makes the window NaN), and preprocess_seq upper-cases and turns T into U,
+    which is what codes 0..3 -> ``ACGU`` gives."""
+
+    def __init__(self, records):
+        packed = records.pack_rna() if hasattr(records, "pack_rna") else None
+        if packed is not None:
+            self.codes, self.offsets, self.lengths = packed
+            self.ids, self.descriptions = records.ids, records.descriptions
+        else:
+            recs = list(records)
+            coded = [pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs]
+            st = pack.pack(coded) if recs else None
+            self.codes = st.codes if st else np.zeros(0, dtype=np.uint8)
+            self.offsets = st.offsets if st else np.zeros(0, dtype=np.int64)
+            self.lengths = st.lengths if st else np.zeros(0, dtype=np.int64)
+            self.ids = [r.id for r in recs]
+            self.descriptions = [r.description for r in recs]
+
+    def __len__(self):
+        return len(self.offsets)
+
+    def select(self, keep):
+        """the batch restricted to records ``keep`` (ascending indices)"""
+        if len(keep) == len(self):
+            return self
+        out = _RnaBatch([])
+        parts = [self.codes[int(self.offsets[i]):int(self.offsets[i] + self.lengths[i]) + 1] for i in keep]
+        out.codes = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+        out.lengths = self.lengths[keep]
+        out.offsets = np.zeros(len(keep), dtype=np.int64)
+        if len(keep) > 1:
+            out.offsets[1:] = np.cumsum(out.lengths[:-1] + 1)
+        out.ids = [self.ids[i] for i in keep]
+        out.descriptions = [self.descriptions[i] for i in keep]
+        return out
+
+
+def _finish(tables, order, sort_keys, columns):
+    """per-motif hit tables (compact columns, table.py) -> one table.  One table is already in (record, Start, motif)
+    order; several are put in record order, then sort_values(sort_keys) inside a record (rnascan.py:286).  Returns
+    the compact columns when asked for (the streaming writer formats them natively), else a DataFrame."""
+    if not tables:
+        return pd.DataFrame(columns=order)
+    if len(tables) == 1:
+        return tables[0] if columns else table.to_frame(tables[0], order)
+    df = pd.concat([table.to_frame(t, ["_rec"] + order) for t in tables], ignore_index=True)
+    df = df.sort_values(["_rec"] + sort_keys, kind="stable").reset_index(drop=True)
+    return df[order]
+
+
+def scan_records(engine, records, pssm, letters, minscore, columns=False):
     """Batch form of scan_all (rnascan.py:278-286) + the per-record tagging of
     scan_main (:401-402): all records in one launch.
 
-    records: iterable of fasta.Record; letters: the alphabet's letters (``GAUC``
+    records: iterable of fasta.Record (or a fasta.FastaSlice); letters: the alphabet's letters (``GAUC``
     for RNA, ``EHTBLRM`` for structure strings).  Returns the hit table with the
-    reference's columns, rows in record order then by Start."""
+    reference's columns, rows in record order then by Start (``columns=True``: possibly as compact columns,
+    see table.py)."""
     is_rna = fasta.is_rna_letters(letters)
-    recs = list(records)
-    if not recs:
+    if not len(records):
         return pd.DataFrame(columns=SEQ_COLUMNS)
-    seqs = [fasta.preprocess_seq(r.seq, is_rna) for r in recs]
     if is_rna:
         order = pack.RNA_LETTERS                               # sorted(alphabet.letters), matrix.py:57
-        codes = [pack.encode_rna(s) for s in seqs]
+        batch = _RnaBatch(records)
+        stream = pack.Stream(batch.codes, None, batch.offsets, batch.lengths)   # packed (and staged on the device) once
+        ids, descriptions = batch.ids, batch.descriptions
+
+        def fragments(pos, rec, start, m):
+            return table.Windows(stream.codes, pos, m, order)
     else:
         order = letters
-        codes = [pack.encode_letters(s, order) for s in seqs]   # _py_calculate upper-cases, matrix.py:31
-    stream = pack.pack(codes)                                  # packed (and staged on the device) once
-    frames = []
+        recs = list(records)
+        seqs = [r.seq for r in recs]                            # structure strings are not upper-cased (rnascan.py:186-197)
+        stream = pack.pack([pack.encode_letters(s, order) for s in seqs])       # _py_calculate upper-cases, matrix.py:31
+        ids, descriptions = [r.id for r in recs], [r.description for r in recs]
+
+        def fragments(pos, rec, start, m):
+            return [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
+    tables = []
 
     def rows(motif_ids, m, pos, mo, logodds):
         rec, start = stream.locate(pos)
-        frag = [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
-        ids = motif_ids[0] if mo is None else np.asarray(motif_ids, dtype=object)[mo]
-        return pd.DataFrame({"_rec": rec, "Sequence_ID": [recs[r].id for r in rec.tolist()],
-                             "Description": [recs[r].description for r in rec.tolist()], "Motif_ID": ids,
-                             "Start": start + 1, "End": start + m, "Sequence": frag, "LogOdds": logodds})
+        return {"_rec": rec, "Sequence_ID": table.Indexed(ids, rec), "Description": table.Indexed(descriptions, rec),
+                "Motif_ID": motif_ids[0] if mo is None else table.Indexed(motif_ids, mo),
+                "Start": start + 1, "End": start + m, "Sequence": fragments(pos, rec, start, m), "LogOdds": logodds}
 
     # An RNA library with a finite threshold goes through the one-pass library kernel, one launch per PFM width
     # (SURVEY 8f N1; the reference's dict only ever holds one motif, rnascan.py:262).  Motifs are ordered by id, so
@@ -170,37 +232,24 @@ def scan_records(engine, records, pssm, letters, minscore):
     by_width = {}
     for motif_id in sorted(pssm.keys()) if len(pssm) > 1 else list(pssm.keys()):
         by_width.setdefault(pssm[motif_id].length, []).append(motif_id)
-    for m, ids in by_width.items():
-        if is_rna and len(ids) > 1 and np.isfinite(float(minscore)):
-            T = np.stack([pssm[i].letter_table(order) for i in ids])
+    for m, mids in by_width.items():
+        if is_rna and len(mids) > 1 and np.isfinite(float(minscore)):
+            T = np.stack([pssm[i].letter_table(order) for i in mids])
             pos, mo, sq, _ = engine.library_hits(stream, T, None, float(minscore))
-            frames.append(rows(ids, m, pos, mo, np.round(sq, 3)))
+            tables.append(rows(mids, m, pos, mo, np.round(sq, 3)))
             continue
-        for motif_id in ids:
-            table = pssm[motif_id].letter_table(order)
+        for motif_id in mids:
+            tab = pssm[motif_id].letter_table(order)
             if is_rna:
-                pos, sq, _ = _select(engine, stream, m, table, None, float(minscore), -np.inf)
+                pos, sq, _ = _select(engine, stream, m, tab, None, float(minscore), -np.inf)
                 logodds = np.round(sq, 3)                      # round(np.float32, 3) stays float32 (rnascan.py:273)
             else:
-                full = engine.scan_letters_f64(stream, table)   # Python floats in the reference: fp64, no f32 cast
+                full = engine.scan_letters_f64(stream, tab)     # Python floats in the reference: fp64, no f32 cast
                 keep = stream.window_mask(m) & (full > float(minscore))
                 pos = np.flatnonzero(keep)
                 logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
-            frames.append(rows([motif_id], m, pos, None, logodds))
-    return _merge_motif_frames(frames)
-
-
-def _merge_motif_frames(frames):
-    """one table per motif -> record order, then sort_values(['Start', 'Motif_ID']) inside a
-    record (rnascan.py:286); with one motif this is the identity"""
-    if not frames:
-        return pd.DataFrame(columns=SEQ_COLUMNS)
-    if len(frames) == 1:
-        df = frames[0]
-    else:
-        df = pd.concat(frames, ignore_index=True)
-        df = df.sort_values(["_rec", "Start", "Motif_ID"], kind="stable").reset_index(drop=True)
-    return df[SEQ_COLUMNS]
+            tables.append(rows([motif_id], m, pos, None, logodds))
+    return _finish(tables, SEQ_COLUMNS, ["Start", "Motif_ID"], columns)
 
 
 def scan(engine, pssm, seq, letters, minscore):
@@ -234,22 +283,21 @@ def struct_matrix(pm, file_letters, pairing="aligned"):
     raise ValueError("pairing must be 'aligned' or 'positional'")
 
 
-def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing):
+def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing, columns=False):
     """hit table of a packed profile stream (no codes): rnascan.py:302-315 for every record
     (and for every motif of a library; the stream is staged on the device once)"""
-    frames = []
+    tables = []
     for motif_id, pm in pssm.items():
         m = pm.length
         P = struct_matrix(pm, list(letters), pairing)
         pos, _, st = _select(engine, stream, m, None, P, -np.inf, float(minscore))
         rec, start = stream.locate(pos)
-        frames.append(pd.DataFrame({"_rec": rec, "Sequence_ID": [ids[r] for r in rec.tolist()], "Description": "",
-                                    "Motif_ID": motif_id, "Start": start + 1, "End": start + m, "Sequence": ".",
-                                    "LogOdds": st}))
-    return _merge_motif_frames(frames)
+        tables.append({"_rec": rec, "Sequence_ID": table.Indexed(ids, rec), "Description": "", "Motif_ID": motif_id,
+                       "Start": start + 1, "End": start + m, "Sequence": ".", "LogOdds": st})
+    return _finish(tables, SEQ_COLUMNS, ["Start", "Motif_ID"], columns)
 
 
-def scan_profiles(engine, named_profiles, pssm, minscore, pairing="aligned", profile_dtype=np.float32):
+def scan_profiles(engine, named_profiles, pssm, minscore, pairing="aligned", profile_dtype=np.float32, columns=False):
     """Batch form of scan_averaged_structure (rnascan.py:293-315) + the tagging of
     scan_main (:367-374).  named_profiles: list of (Sequence_ID, letters, [L][7])."""
     if not named_profiles:
@@ -259,17 +307,17 @@ def scan_profiles(engine, named_profiles, pssm, minscore, pairing="aligned", pro
         if list(letters) != letters0:
             raise ValueError("averaged-structure files disagree on their column order")
     stream = pack.pack(profiles=[p for _, _, p in named_profiles], profile_dtype=profile_dtype)
-    return _scan_profile_stream(engine, stream, [n for n, _, _ in named_profiles], letters0, pssm, minscore, pairing)
+    return _scan_profile_stream(engine, stream, [n for n, _, _ in named_profiles], letters0, pssm, minscore, pairing, columns)
 
 
-def scan_store(engine, profile_store, pssm, minscore, pairing="aligned", lo=0, hi=None):
+def scan_store(engine, profile_store, pssm, minscore, pairing="aligned", lo=0, hi=None, columns=False):
     """Same table from a packed profile store (rnascan_amd/store.py): the mapped file
     already IS the stream layout, nothing is parsed or repacked."""
     hi = len(profile_store.ids) if hi is None else hi
     if hi <= lo:
         return pd.DataFrame(columns=SEQ_COLUMNS)
     return _scan_profile_stream(engine, profile_store.stream(lo, hi), profile_store.ids[lo:hi], profile_store.letters,
-                                pssm, minscore, pairing)
+                                pssm, minscore, pairing, columns)
 
 
 def scan_averaged_structure(engine, struct_file, pssm, minscore, pairing="aligned", profile_dtype=np.float64):
@@ -337,7 +385,7 @@ def pair_motifs(seq_pssm, struct_pssm):
 
 
 def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minscore, pairing="aligned",
-                  profile_dtype=np.float32):
+                  profile_dtype=np.float32, columns=False, prepacked=None):
     """Sequence PFMs + averaged-structure PFMs in ONE pass per PFM width (configs 3 and 5).
 
     Equivalent to ``combine(scan_main(fasta), scan_main(dir))`` for the records
@@ -345,66 +393,81 @@ def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minsco
     is reported for the motif pair (a, b) iff seq_a > minscore AND struct_b > minscore
     (rnascan.py:422-433 is an inner join of two independently thresholded tables); which pairs
     exist is ``pair_motifs``.  Returns None when the inputs cannot be paired one to one (duplicate ids,
-    length mismatch, unpairable libraries); callers then take the two-table path."""
+    length mismatch, unpairable libraries); callers then take the two-table path.
+
+    ``prepacked`` = (ids, letters, pack.Stream) instead of ``named_profiles``: the profiles of exactly these records,
+    in this order, already in stream form (a slice of a packed profile store) -- used as they are when ids and
+    lengths agree, no per-record copy."""
     pairs_m = pair_motifs(seq_pssm, struct_pssm)
     if pairs_m is None:
         return None
-    recs = list(records)
+    if prepacked is not None:
+        pids, letters0, pst = prepacked
+        batch = _RnaBatch(records)
+        if pairs_m and len(batch) and list(batch.ids) == list(pids) and len(set(pids)) == len(pids) and \
+                np.array_equal(batch.lengths, pst.lengths):
+            prof = pst.profile if pst.profile.dtype == np.dtype(profile_dtype) else np.asarray(pst.profile, dtype=profile_dtype)
+            stream = pack.Stream(batch.codes, prof, batch.offsets, batch.lengths)
+            return _scan_combined_stream(engine, stream, batch, list(letters0), pairs_m, seq_pssm, struct_pssm, minscore, pairing,
+                                         columns)
+        named_profiles = [(pids[r], letters0, pst.profile[int(pst.offsets[r]):int(pst.offsets[r] + pst.lengths[r])])
+                          for r in range(len(pids))]
     by_id = {}
     for sid, letters, prof in named_profiles:
         if sid in by_id:
             return None
         by_id[sid] = (letters, prof)
-    if len(set(r.id for r in recs)) != len(recs):
+    batch = _RnaBatch(records)
+    all_ids = list(batch.ids)
+    if len(set(all_ids)) != len(all_ids):
         return None
-    pairs = [(r, by_id[r.id]) for r in recs if r.id in by_id]
-    if not pairs or not pairs_m:
+    keep = [i for i, rid in enumerate(all_ids) if rid in by_id]
+    if not keep or not pairs_m:
         return pd.DataFrame(columns=COMBINED_COLUMNS)
-    letters0 = list(pairs[0][1][0])
-    seqs, codes, profs = [], [], []
-    for r, (letters, prof) in pairs:
-        s = fasta.preprocess_seq(r.seq, True)
-        if len(s) != prof.shape[0] or list(letters) != letters0:
+    batch = batch.select(np.asarray(keep, dtype=np.int64))
+    letters0 = list(by_id[batch.ids[0]][0])
+    profs = []
+    for k, rid in enumerate(batch.ids):
+        letters, prof = by_id[rid]
+        if int(batch.lengths[k]) != prof.shape[0] or list(letters) != letters0:
             return None
-        seqs.append(s)
-        codes.append(pack.encode_rna(s))
         profs.append(prof)
-    stream = pack.pack(codes, profs, profile_dtype=profile_dtype)
+    stream = pack.Stream(batch.codes, pack.pack(profiles=profs, profile_dtype=profile_dtype).profile, batch.offsets, batch.lengths)
+    return _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, struct_pssm, minscore, pairing, columns)
+
+
+def _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, struct_pssm, minscore, pairing, columns):
+    """the combined hit table of one packed batch (codes + profile rows of the same records)"""
     thr = float(minscore)
-    frames = []
+    tables = []
     by_width = {}
     for a, b in pairs_m:
         by_width.setdefault(seq_pssm[a].length, []).append((a, b))
     for m, group in by_width.items():
-        tables = [seq_pssm[a].letter_table(pack.RNA_LETTERS) for a, _ in group]
+        tabs = [seq_pssm[a].letter_table(pack.RNA_LETTERS) for a, _ in group]
         pssms = [struct_matrix(struct_pssm[b], letters0, pairing) for _, b in group]
         if len(group) > 1 and np.isfinite(thr):
-            pos, mo, sq, st = engine.library_hits(stream, np.stack(tables), np.stack(pssms), thr, thr)
+            pos, mo, sq, st = engine.library_hits(stream, np.stack(tabs), np.stack(pssms), thr, thr)
             parts = [(pos, mo, sq, st)]
         else:
             parts = []
             for k in range(len(group)):
-                pos, sq, st = _select(engine, stream, m, tables[k], pssms[k], thr, thr)
+                pos, sq, st = _select(engine, stream, m, tabs[k], pssms[k], thr, thr)
                 parts.append((pos, np.full(pos.size, k, dtype=np.int32), sq, st))
         for pos, mo, sq, st in parts:
             rec, start = stream.locate(pos)
-            rl, sl = rec.tolist(), start.tolist()
             lo_seq = np.round(sq, 3)
-            frames.append(pd.DataFrame({
+            tables.append({
                 "_rec": rec,
-                "Sequence_ID": [pairs[r][0].id for r in rl],
-                "Description.Seq": [pairs[r][0].description for r in rl],
-                "Motif_ID.Seq": np.asarray([a for a, _ in group], dtype=object)[mo], "Start": start + 1, "End": start + m,
-                "Sequence.Seq": [seqs[r][s:s + m] for r, s in zip(rl, sl)],
+                "Sequence_ID": table.Indexed(batch.ids, rec),
+                "Description.Seq": table.Indexed(batch.descriptions, rec),
+                "Motif_ID.Seq": table.Indexed([a for a, _ in group], mo), "Start": start + 1, "End": start + m,
+                "Sequence.Seq": table.Windows(stream.codes, pos, m, pack.RNA_LETTERS),
                 "LogOdds.Seq": lo_seq, "Description.Struct": "",
-                "Motif_ID.Struct": np.asarray([b for _, b in group], dtype=object)[mo], "Sequence.Struct": ".",
-                "LogOdds.Struct": st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + st}))
-    if len(frames) == 1:
-        df = frames[0]                      # (position, pair index) order = (record, Start, Motif_ID.Seq, Motif_ID.Struct)
-    else:
-        df = pd.concat(frames, ignore_index=True)
-        df = df.sort_values(["_rec", "Start", "Motif_ID.Seq", "Motif_ID.Struct"], kind="stable").reset_index(drop=True)
-    return df[COMBINED_COLUMNS]
+                "Motif_ID.Struct": table.Indexed([b for _, b in group], mo), "Sequence.Struct": ".",
+                "LogOdds.Struct": st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + st})
+    # one table: (position, pair index) order = (record, Start, Motif_ID.Seq, Motif_ID.Struct)
+    return _finish(tables, COMBINED_COLUMNS, ["Start", "Motif_ID.Seq", "Motif_ID.Struct"], columns)
 
 
 def _add_match_id(df):

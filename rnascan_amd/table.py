@@ -7,9 +7,76 @@ table has 10^8+ rows and the DataFrames dwarf the scan.  ``TsvWriter`` writes th
 bytes -- same column order, ``Match_ID`` appended last and numbered 1..n across chunks
 (rnascan.py:329-332), float32 scores as the shortest float32 repr (``14.259``), float64
 scores as ``repr(float)``, NaN as the empty field -- from column arrays, one chunk (one
-shard, one batch) at a time, without ever holding the whole table.
+shard, one batch) at a time, without ever holding the whole table.  The rows are formatted
+by ``pfmscan_tsv_format`` (native, parallel); the scanners hand over their hit columns in
+the compact forms below, so no per-row Python object is ever made on the streaming path.
 """
 import numpy as np
+
+from . import _lib
+
+
+class Indexed(object):
+    """A string column given as (values, index): row r holds ``values[index[r]]`` (record ids, descriptions,
+    motif ids -- one Python string per distinct value instead of one per row)."""
+
+    def __init__(self, values, index):
+        self.values = values
+        self.index = np.asarray(index, dtype=np.int64)
+
+    def __len__(self):
+        return self.index.shape[0]
+
+    def materialize(self):
+        used, inv = np.unique(self.index, return_inverse=True)
+        vals = np.empty(used.size, dtype=object)
+        vals[:] = [self.values[i] for i in used.tolist()]
+        return vals[inv]
+
+
+class Windows(object):
+    """The ``Sequence`` column given as stream positions into a code array: row r holds the ``m`` letters
+    ``letters[codes[pos[r] + j]]`` (rnascan.py:272 slices the record string per hit)."""
+
+    def __init__(self, codes, pos, m, letters):
+        self.codes = codes
+        self.pos = np.asarray(pos, dtype=np.int64)
+        self.m = int(m)
+        self.letters = letters
+
+    def __len__(self):
+        return self.pos.shape[0]
+
+    def materialize(self):
+        lut = np.frombuffer(self.letters.ljust(8, "?").encode("ascii"), dtype=np.uint8)
+        if self.pos.size == 0 or self.m == 0:
+            return np.full(self.pos.size, "", dtype=object)
+        win = lut[self.codes[self.pos[:, None] + np.arange(self.m)] & 7]
+        return np.ascontiguousarray(win).view("S%d" % self.m).reshape(-1).astype(str).astype(object)
+
+
+def column_length(col):
+    if isinstance(col, (Indexed, Windows)):
+        return len(col)
+    if isinstance(col, str) or np.ndim(col) == 0:
+        return None
+    return len(col)
+
+
+def to_frame(columns, order=None):
+    """compact columns -> pandas DataFrame (the non-streaming consumers: joins, multi-rank gathers, the API)"""
+    import pandas as pd
+    order = list(order or columns.keys())
+    n = next((k for k in (column_length(columns[c]) for c in order) if k is not None), 0)
+    data = {}
+    for c in order:
+        col = columns[c]
+        if isinstance(col, (Indexed, Windows)):
+            col = col.materialize()
+        elif column_length(col) is None:
+            col = np.full(n, col, dtype=object if isinstance(col, str) else None)
+        data[c] = col
+    return pd.DataFrame(data, columns=order)
 
 
 def _quote(field):
@@ -21,34 +88,59 @@ def _quote(field):
     return field
 
 
-def _strings(col, n):
-    """column -> list of n field strings, formatted the way pandas' to_csv does"""
+def _blob(strings):
+    """list of field strings -> (offsets int64 [n + 1], utf-8 bytes)"""
+    enc = [_quote(s).encode("utf-8") for s in strings]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    if enc:
+        np.cumsum([len(e) for e in enc], out=off[1:])
+    return off, b"".join(enc)
+
+
+def _descriptor(col, n):
+    """one column -> (kind, data, aux, blob, width) of pfmscan_tsv_format, formatted the way pandas' to_csv does"""
     if isinstance(col, str):
-        return [_quote(col)] * n
+        b = _quote(col).encode("utf-8")
+        return (_lib.TSV_CONST, b, None, None, len(b))
+    if isinstance(col, Indexed):
+        if len(col) != n:
+            raise ValueError("column length mismatch")
+        # only the values some row uses are stringified
+        used, inv = np.unique(col.index, return_inverse=True)
+        off, blob = _blob([col.values[i] for i in used.tolist()])
+        return (_lib.TSV_INDEXED, inv.astype(np.int64), off, blob, 0)
+    if isinstance(col, Windows):
+        if len(col) != n:
+            raise ValueError("column length mismatch")
+        return (_lib.TSV_WINDOW, col.pos, col.codes, col.letters.ljust(8, "?").encode("ascii"), col.m)
     if isinstance(col, (list, tuple)):
         if len(col) != n:
             raise ValueError("column length mismatch")
         if col and not isinstance(col[0], str):
-            return _strings(np.asarray(col), n)
-        return [_quote(x) for x in col]
+            return _descriptor(np.asarray(col), n)
+        off, blob = _blob(col)
+        return (_lib.TSV_INDEXED, np.arange(n, dtype=np.int64), off, blob, 0)
     a = np.asarray(col)
     if a.ndim == 0:
-        return [_strings(a.reshape(1), 1)[0]] * n
+        return _descriptor(a.reshape(1).repeat(n), n) if a.dtype.kind in "fiu" else _descriptor(str(a.item()), n)
     if a.shape[0] != n:
         raise ValueError("column length mismatch")
+    if a.dtype == np.float32:
+        return (_lib.TSV_F32, a, None, None, 0)
     if a.dtype.kind == "f":
-        s = a.astype(str)                       # shortest repr of the column's own precision
-        if np.isnan(a).any():
-            s = s.astype(object)
-            s[np.isnan(a)] = ""                 # na_rep=''
-        return s.tolist()
+        return (_lib.TSV_F64, a.astype(np.float64, copy=False), None, None, 0)
     if a.dtype.kind in "iu":
-        return a.astype(str).tolist()
-    return [_quote(x) if isinstance(x, str) else str(x) for x in a.tolist()]
+        return (_lib.TSV_I64, a.astype(np.int64, copy=False), None, None, 0)
+    if a.dtype.kind == "S":
+        return (_lib.TSV_FIXED, a, None, None, a.dtype.itemsize)
+    strings = [x if isinstance(x, str) else ("" if x is None or (isinstance(x, float) and x != x) else str(x)) for x in a.tolist()]
+    off, blob = _blob(strings)
+    return (_lib.TSV_INDEXED, np.arange(n, dtype=np.int64), off, blob, 0)
 
 
 class TsvWriter(object):
-    """write_chunk(columns) appends rows; columns is an ordered mapping name -> array | list | scalar."""
+    """write_chunk(columns) appends rows; columns is an ordered mapping name -> array | list | scalar |
+    Indexed | Windows (a DataFrame's columns work as arrays)."""
 
     def __init__(self, out, columns, match_id=True):
         self.out = out
@@ -59,14 +151,17 @@ class TsvWriter(object):
 
     def write_chunk(self, data, n=None):
         if n is None:
-            n = len(next(v for v in data.values() if not isinstance(v, str) and np.ndim(v) > 0))
+            n = next((k for k in (column_length(data[c]) for c in self.columns) if k is not None), 0)
         if n == 0:
             return
-        cols = [_strings(data[c], n) for c in self.columns]
-        if self.match_id:
-            cols.append(np.arange(self.rows + 1, self.rows + n + 1).astype(str).tolist())
-        self.out.write("\n".join("\t".join(t) for t in zip(*cols)))
-        self.out.write("\n")
+        desc = [_descriptor(data[c], n) for c in self.columns]
+        text = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1)
+        raw = getattr(self.out, "buffer", None)
+        if raw is not None and getattr(self.out, "encoding", "utf-8").lower().replace("-", "") == "utf8":
+            self.out.flush()
+            raw.write(text)                      # a text stream over a byte stream: no decode / re-encode of the rows
+        else:
+            self.out.write(text.decode("utf-8"))
         self.rows += n
 
 

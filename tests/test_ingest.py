@@ -1,0 +1,185 @@
+"""Native host ingest / output (pfmscan_fasta_index, pfmscan_fasta_encode, pfmscan_tsv_format; no device needed)
+against the Python statements of the same behaviour: parse_sequences + preprocess_seq + encode_rna
+(rnascan.py:170-174, :177-204, _pwm.c:41-63) and DataFrame.to_csv(sep='\\t', index=False) (rnascan.py:555-567)."""
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from rnascan_amd import _lib, fasta, pack, table
+
+NASTY = (b"junk before the first header\nACGT\n"
+         b">r1 first record\r\nACGTacgu\r\n  AC GU \t\n\n"
+         b">r2\n"
+         b">r3 only\x0bodd white\tspace\nNNNN\x0b\nAC\tGU\n"
+         b">\nAC>GU\n"
+         b">r5 caf\xc3\xa9 \"quoted\"\tTAB\n" + b"ACGU" * 50 + b"\n" + b"acgt" * 50 + b"\n"
+         b">last no newline\nGGGG")
+
+
+def _reference_pack(path):
+    recs = list(fasta.parse_sequences(path))
+    codes = [pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs]
+    return recs, pack.pack(codes)
+
+
+def _write(tmp_path, name, data):
+    p = os.path.join(str(tmp_path), name)
+    with open(p, "wb") as f:
+        f.write(data)
+    return p
+
+
+@pytest.mark.parametrize("data", [NASTY, b"", b"no header at all\nACGU\n", b">only header", b">a\nAC\n>b\nGU\n", b"\n\n>x\n\n\nA\n\n"])
+def test_native_fasta_matches_the_python_parser(tmp_path, data):
+    path = _write(tmp_path, "a.fa", data)
+    recs, want = _reference_pack(path) if data else ([], None)
+    lazy = fasta.LazyFasta(path)
+    assert len(lazy) == len(recs)
+    assert list(lazy.ids) == [r.id for r in recs]
+    assert list(lazy.headers) == [r.description for r in recs]
+    assert lazy.lengths == [len(r.seq) for r in recs]
+    assert [tuple(r) for r in lazy] == [tuple(r) for r in recs]
+    if not recs:
+        return
+    codes, offsets, lengths = lazy[0:len(lazy)].pack_rna()
+    assert np.array_equal(codes, want.codes) and np.array_equal(offsets, want.offsets) and np.array_equal(lengths, want.lengths)
+    for lo in range(len(recs)):                       # every sub-range, every thread count
+        for hi in range(lo, len(recs) + 1):
+            sub = lazy[lo:hi]
+            assert [tuple(r) for r in sub] == [tuple(r) for r in recs[lo:hi]]
+            assert list(sub.ids) == [r.id for r in recs[lo:hi]]
+            c, o, ln = sub.pack_rna()
+            ref = pack.pack([pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs[lo:hi]]) if hi > lo else None
+            if ref is None:
+                assert c.size == 0 and o.size == 0
+            else:
+                assert np.array_equal(c, ref.codes) and np.array_equal(o, ref.offsets) and np.array_equal(ln, ref.lengths)
+
+
+line = st.one_of(
+    st.text(alphabet="ACGUTacgutNn", min_size=0, max_size=30),
+    st.text(alphabet="ACGU \t>x", min_size=0, max_size=12),
+    st.builds(lambda s: ">" + s, st.text(alphabet="ab1 \t_|", min_size=0, max_size=10)))
+
+
+@settings(max_examples=150, deadline=None)
+@given(lines=st.lists(line, min_size=0, max_size=25), eol=st.sampled_from(["\n", "\r\n"]), tail=st.booleans(),
+       threads=st.integers(1, 5))
+def test_native_fasta_property(tmp_path_factory, lines, eol, tail, threads):
+    data = eol.join(lines).encode("latin-1") + (eol.encode() if tail else b"")
+    path = _write(tmp_path_factory.mktemp("fa"), "p.fa", data)
+    recs = list(fasta.parse_sequences(path))
+    buf = np.frombuffer(data, dtype=np.uint8)
+    ix = _lib.fasta_index(buf)
+    assert ix[0].size == len(recs)
+    assert ix[4].tolist() == [len(r.seq) for r in recs]
+    assert [data[o:o + n].decode("latin-1") for o, n in zip(ix[0].tolist(), ix[1].tolist())] == [r.description for r in recs]
+    if recs:
+        codes, offsets = _lib.fasta_encode(buf, ix[2], ix[3], ix[4], 0, len(recs), pack._RNA_LUT, pack.SEP, threads)
+        ref = pack.pack([pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs])
+        assert np.array_equal(codes, ref.codes) and np.array_equal(offsets, ref.offsets)
+
+
+def test_lazy_fasta_over_several_files_and_compressed_input(tmp_path):
+    import gzip
+    a = _write(tmp_path, "a.fa", b">a1\nACGU\n>a2\nGG\n")
+    b = _write(tmp_path, "b.fa", b">b1 x\nUUUU\nAA\n")
+    with gzip.open(os.path.join(str(tmp_path), "c.fa.gz"), "wb") as f:
+        f.write(b">c1\nACGT\n")
+    lazy = fasta.LazyFasta([a, b])
+    assert list(lazy.ids) == ["a1", "a2", "b1"] and lazy.lengths == [4, 2, 6]
+    codes, offsets, lengths = lazy[1:3].pack_rna()
+    assert codes.tolist() == [2, 2, 7, 3, 3, 3, 3, 0, 0, 7] and offsets.tolist() == [0, 3] and lengths.tolist() == [2, 6]
+    mixed = fasta.LazyFasta([a, os.path.join(str(tmp_path), "c.fa.gz")])
+    assert list(mixed.ids) == ["a1", "a2", "c1"]
+    assert mixed[0:3].pack_rna() is None                 # a compressed file has no mapped bytes: the Record path is taken
+    assert mixed[0:2].pack_rna() is not None
+    assert [r.seq for r in mixed] == ["ACGU", "GG", "ACGT"]
+
+
+def test_fasta_index_argument_errors():
+    L = _lib.load()
+    assert L.pfmscan_fasta_index(None, 5, 0, None, None, None, None, None, None) == _lib.E_BADARG
+    buf = np.frombuffer(b">a\nAC\n>b\nGU\n", dtype=np.uint8)
+    ix = _lib.fasta_index(buf)
+    wrong = ix[4].copy()
+    wrong[0] = 1                                         # an index that does not describe the bytes
+    with pytest.raises(ValueError):
+        _lib.fasta_encode(buf, ix[2], ix[3], wrong, 0, 2, pack._RNA_LUT)
+    with pytest.raises(ValueError):
+        _lib.fasta_encode(buf, ix[2], ix[3], ix[4], 0, 2, np.zeros(10, dtype=np.uint8))
+
+
+def _float_strings(a):
+    return "\n".join(a.astype(str).tolist()).replace("nan", "") + "\n"
+
+
+@pytest.mark.parametrize("dtype,bits", [(np.float32, np.uint32), (np.float64, np.uint64)])
+def test_float_fields_are_numpys_shortest_repr(dtype, bits):
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, np.iinfo(bits).max, size=200000, dtype=bits).view(dtype)            # every exponent, both signs
+    with np.errstate(over="ignore"):
+        special = np.array([0.0, -0.0, 1.0, -1.0, 6.0, 14.259, 1e-4, 9.999e-5, 1e-5, 1e15, 1e16, 9.999999e15, 123456.789, 0.001,
+                            np.inf, -np.inf, np.nan, 5e-324, 1.7976931348623157e308, 1e22, 1e23, 0.1, 0.3, 2.5e-7], dtype=dtype)
+    scores = np.round(rng.normal(0, 10, size=100000).astype(dtype), 3)                        # what LogOdds columns hold
+    a = np.concatenate([special, scores, raw])
+    got = bytes(_lib.tsv_format([(_lib.TSV_F32 if dtype == np.float32 else _lib.TSV_F64, a, None, None, 0)], a.size)).decode()
+    assert got == _float_strings(a)
+    if dtype == np.float64:                                                                   # = repr(float), what to_csv writes
+        fin = a[np.isfinite(a)][:5000]
+        assert bytes(_lib.tsv_format([(_lib.TSV_F64, fin, None, None, 0)], fin.size)).decode() == "".join(repr(float(x)) + "\n" for x in fin)
+
+
+def test_writer_bytes_equal_to_csv(tmp_path):
+    rng = np.random.default_rng(9)
+    n = 5000
+    ids = ["rec%d" % i for i in range(40)] + ['we"ird', "tab\there", "line\nbreak", "café", ""]
+    rec = np.sort(rng.integers(0, len(ids), size=n))
+    codes = rng.integers(0, 4, size=4000).astype(np.uint8)
+    pos = rng.integers(0, 4000 - 12, size=n)
+    f32 = np.round(rng.normal(0, 8, size=n).astype(np.float32), 3)
+    f64 = rng.normal(0, 8, size=n)
+    f64[::97] = np.nan
+    f64[5] = np.inf
+    cols = {"Sequence_ID": table.Indexed(ids, rec), "Description": table.Indexed([s + " desc" for s in ids], rec),
+            "Motif_ID": "motif\tX", "Start": pos + 1, "End": pos + 12, "Sequence": table.Windows(codes, pos, 12, "ACGU"),
+            "LogOdds": f32, "Struct": f64, "Sum": f32.astype(np.float64) + f64, "Dot": "."}
+    df = table.to_frame(cols)
+    assert df["Sequence"].tolist()[:3] == ["".join("ACGU"[c] for c in codes[p:p + 12]) for p in pos[:3]]
+    want = df.copy()
+    want["Match_ID"] = np.arange(1, n + 1)
+    expected = want.to_csv(sep="\t", index=False)
+    out = io.StringIO()
+    w = table.TsvWriter(out, list(cols))
+    w.write_chunk(cols)
+    assert out.getvalue() == expected
+    out = io.StringIO()                                  # the same table as a DataFrame, in uneven chunks
+    table.write_frame(out, df, chunk=777)
+    assert out.getvalue() == expected
+    path = os.path.join(str(tmp_path), "o.tsv")          # a real text file: rows go to its byte buffer
+    with open(path, "w", encoding="utf-8", newline="") as f:
+        w = table.TsvWriter(f, list(cols))
+        for lo in range(0, n, 1234):
+            part = {k: (v if isinstance(v, str) else
+                        table.Indexed(v.values, v.index[lo:lo + 1234]) if isinstance(v, table.Indexed) else
+                        table.Windows(v.codes, v.pos[lo:lo + 1234], v.m, v.letters) if isinstance(v, table.Windows) else
+                        v[lo:lo + 1234]) for k, v in cols.items()}
+            w.write_chunk(part)
+    with open(path, "r", encoding="utf-8", newline="") as f:
+        assert f.read() == expected
+
+
+def test_tsv_format_capacity_and_bad_descriptors():
+    L = _lib.load()
+    a = np.arange(1000, dtype=np.int64)
+    text = _lib.tsv_format([(_lib.TSV_I64, a, None, None, 0)], a.size, 1, estimate=16)        # grows after E_CAPACITY
+    assert bytes(text).decode() == "".join("%d\t%d\n" % (i, i + 1) for i in range(1000))
+    with pytest.raises(ValueError):
+        _lib.tsv_format([(9, a, None, None, 0)], a.size)
+    with pytest.raises(ValueError):
+        _lib.tsv_format([(_lib.TSV_INDEXED, a, None, None, 0)], a.size)
+    assert L.pfmscan_tsv_format(None, 1, 1, -1, None, 0, None, 0) == _lib.E_BADARG

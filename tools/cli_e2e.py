@@ -6,6 +6,7 @@ import numpy as np
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+RBIG = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # a second, sequence-only FASTA of this many records
 from rnascan_amd import cli, store
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
 d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
@@ -30,16 +31,34 @@ with open(os.path.join(sd, "profile.f32"), "wb") as f:
 json.dump({"format": 1, "dtype": "float32", "letters": list("BEHLMRT"), "ids": ["t%d" % i for i in range(R)],
            "lengths": [L] * R, "n_pos": R * (L + 1), "file": "profile.f32", "separator_rows": "one zero row after each record"},
           open(os.path.join(sd, "index.json"), "w"))
+big = os.path.join(d, "big.fa")
+if RBIG:
+    with open(big, "wb") as f:
+        for lo in range(0, RBIG, 2000):
+            n = min(2000, RBIG - lo)
+            body = letters[rng.integers(0, 4, size=(n, L))]
+            f.write(b"".join(b">t%d transcript %d\n" % (lo + i, lo + i) + body[i].tobytes() + b"\n" for i in range(n)))
 print("inputs written in %.1f s (%s)" % (time.time() - t0, d), file=sys.stderr)
-for name, argv in (
+runs = [
     ("seq only  -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", fa]),
     ("struct only (store) -m 6", ["-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", sd]),
     ("seq + struct (store) -m 0", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"),
                                    "-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", "0",
                                    "--profile-dtype", "float32", fa, sd]),
-):
-    out = io.StringIO()
-    t = time.time()
-    cli.main(argv, out=out)
-    dt = time.time() - t
-    print("%-28s %.2f s   %d rows   %.3g windows/s" % (name, dt, out.getvalue().count("\n") - 1, R * (L - 17) / dt))
+    ("seq + struct (store) -m -4", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"),
+                                    "-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", " -4",
+                                    "--profile-dtype", "float32", fa, sd]),
+]
+if RBIG:
+    runs += [("big: seq only -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", big]),
+             ("big: seq only -m 2", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", "-m", "2", big])]
+for name, argv in runs:
+    nrec = RBIG if name.startswith("big") else R
+    path = os.path.join(d, "out.tsv")
+    with open(path, "w", encoding="utf-8", newline="") as out:
+        t = time.time()
+        cli.main(argv, out=out)
+        dt = time.time() - t
+    rows = sum(1 for _ in open(path, "rb")) - 1
+    print("%-28s %.2f s   %d rows   %.3g windows/s   %.1f MB of table" % (name, dt, rows, nrec * (L - 17) / dt,
+                                                                         os.path.getsize(path) / 1e6))
