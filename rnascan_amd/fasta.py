@@ -281,6 +281,25 @@ def preprocess_seq(seq, target_is_rna, source_is_rna=False):
     return seq
 
 
+def _count_rna_natively(fasta_files, positions=1 << 26):
+    """A, C, G, U counts of plain FASTA files through the native packer (batches of ``positions`` letters), or None
+    when a file is compressed"""
+    files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
+    if any(os.path.splitext(f)[1] in (".gz", ".bz2") for f in files):
+        return None
+    lazy = LazyFasta(files)
+    counts = np.zeros(8, dtype=np.int64)
+    lo = 0
+    while lo < len(lazy):
+        hi, acc = lo, 0
+        while hi < len(lazy) and (hi == lo or acc + lazy.lengths[hi] < positions):
+            acc += lazy.lengths[hi] + 1
+            hi += 1
+        counts += np.bincount(lazy[lo:hi].pack_rna()[0], minlength=8)
+        lo = hi
+    return counts[:4]
+
+
 def compute_background(fasta_files, letters, verbose=True):
     """rnascan.py:440-465: letter counts over all (preprocessed) records with a
     +1 pseudocount per alphabet letter."""
@@ -288,12 +307,18 @@ def compute_background(fasta_files, letters, verbose=True):
     content = {}
     total = len(letters)
     is_rna = is_rna_letters(letters)
-    for rec in parse_sequences(fasta_files):
-        s = preprocess_seq(rec.seq, is_rna)
+    counted = _count_rna_natively(fasta_files) if is_rna else None
+    if counted is not None:                    # the same counts from the packed codes (preprocess_seq + count, natively)
         for letter in letters:
-            amount = s.count(letter)
-            content[letter] = content.get(letter, 0) + amount
-            total += amount
+            content[letter] = int(counted[pack.RNA_LETTERS.index(letter)])
+            total += content[letter]
+    else:
+        for rec in parse_sequences(fasta_files):
+            s = preprocess_seq(rec.seq, is_rna)
+            for letter in letters:
+                amount = s.count(letter)
+                content[letter] = content.get(letter, 0) + amount
+                total += amount
     pct_sum = 0.0
     for letter, count in content.items():
         content[letter] = (float(count) + 1) / total

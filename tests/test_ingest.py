@@ -183,3 +183,17 @@ def test_tsv_format_capacity_and_bad_descriptors():
     with pytest.raises(ValueError):
         _lib.tsv_format([(_lib.TSV_INDEXED, a, None, None, 0)], a.size)
     assert L.pfmscan_tsv_format(None, 1, 1, -1, None, 0, None, 0) == _lib.E_BADARG
+
+
+def test_background_counts_natively_equal_the_record_loop(tmp_path):
+    path = _write(tmp_path, "bg.fa", NASTY)
+    want = {l: 0 for l in fasta.RNA}
+    for rec in fasta.parse_sequences(path):
+        s = fasta.preprocess_seq(rec.seq, True)
+        for l in fasta.RNA:
+            want[l] += s.count(l)
+    got = fasta._count_rna_natively(path, positions=64)             # several batches
+    assert {l: int(got[pack.RNA_LETTERS.index(l)]) for l in fasta.RNA} == want
+    total = sum(want.values()) + 4
+    bg = fasta.compute_background(path, fasta.RNA, verbose=False)
+    assert bg == {l: (want[l] + 1.0) / total for l in fasta.RNA}
