@@ -277,6 +277,11 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
 int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t *hdr_off,
                         int64_t *hdr_len, int64_t *seq_off, int64_t *seq_end, int64_t *n_letters,
                         int64_t *n_records);
+ /* pfmscan_fasta_ids: the id of every record = the first whitespace-separated word of its header
+  *   (id_off, id_len: byte span in buf); *all_ascii = 0 when some header holds a byte >= 0x80 (the caller then
+  *   decodes the headers itself). */
+int pfmscan_fasta_ids(const uint8_t *buf, const int64_t *hdr_off, const int64_t *hdr_len,
+                      int64_t n_records, int64_t *id_off, int64_t *id_len, int *all_ascii);
 int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64_t *seq_end,
                          const int64_t *n_letters, int64_t lo, int64_t hi, const uint8_t *lut256,
                          int separator, uint8_t *codes, int64_t *offsets, int n_threads);
@@ -293,6 +298,9 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
  *   FIXED    data = bytes [n_rows][width], trailing NULs dropped (numpy 'S' arrays)
  *   WINDOW   data = int64 stream positions [n_rows], aux = the code stream, blob = 8 letters: the `width` letters
  *            blob[code & 7] of the window at each position (the Sequence column)
+ *   SPAN     data = int64 index [n_rows], aux = int64 [n_values][2] (offset, length) into blob: row r holds those
+ *            bytes of blob (ids / headers straight from the mapped FASTA), csv-quoted here when they hold a tab, a
+ *            double quote or a line break
  * first_match_id >= 0 appends a last column counting up from it.  Every row ends in '\n'; no header line.
  * PFMSCAN_E_CAPACITY: *n_bytes holds the size that suffices, nothing was written. */
 #define PFMSCAN_TSV_CONST   0
@@ -302,6 +310,7 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
 #define PFMSCAN_TSV_INDEXED 4
 #define PFMSCAN_TSV_FIXED   5
 #define PFMSCAN_TSV_WINDOW  6
+#define PFMSCAN_TSV_SPAN    7
 typedef struct pfmscan_tsv_column {
     int32_t kind;
     int32_t reserved;

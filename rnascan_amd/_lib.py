@@ -33,9 +33,9 @@ SYMBOLS = [
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
-    "pfmscan_fasta_index", "pfmscan_fasta_encode", "pfmscan_tsv_format",
+    "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_fasta_encode", "pfmscan_tsv_format",
 ]
-TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW = range(7)
+TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
 
 class TsvColumn(ctypes.Structure):
@@ -122,6 +122,7 @@ def load():
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), i32]
     for name in SYMBOLS:          # every other entry point returns a status
@@ -171,6 +172,18 @@ def fasta_index(buf):
         if rc != OK:
             _raise(L, None, rc)
     return tuple(cols)
+
+
+def fasta_ids(buf, hdr_off, hdr_len):
+    """(id spans int64 [n][2] = (offset, length) of every record's first header word, all headers ASCII?)"""
+    L = load()
+    n = int(hdr_off.size)
+    off, ln = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+    ascii_ = ctypes.c_int(1)
+    rc = L.pfmscan_fasta_ids(_ptr(np.asarray(buf)), _ptr(hdr_off), _ptr(hdr_len), n, _ptr(off), _ptr(ln), ctypes.byref(ascii_))
+    if rc != OK:
+        _raise(L, None, rc)
+    return np.stack([off, ln], axis=1), bool(ascii_.value)
 
 
 def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, threads=0):

@@ -156,6 +156,31 @@ int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t
     return PFMSCAN_OK;
 }
 
+int pfmscan_fasta_ids(const uint8_t *buf, const int64_t *hdr_off, const int64_t *hdr_len, int64_t n_records, int64_t *id_off,
+                      int64_t *id_len, int *all_ascii)
+{
+    if (n_records < 0 || (n_records > 0 && (!buf || !hdr_off || !hdr_len || !id_off || !id_len)) || !all_ascii)
+        return fail(nullptr, PFMSCAN_E_BADARG, "fasta_ids: bad argument");
+    // str.split(None, 1)[0] on ASCII text: whitespace is \t \n \v \f \r, \x1c..\x1f and the blank
+    auto ws = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); };
+    int ascii = 1;
+    for (int64_t r = 0; r < n_records; ++r) {
+        const uint8_t *h = buf + hdr_off[r];
+        const int64_t n = hdr_len[r];
+        int64_t a = 0;
+        while (a < n && ws(h[a])) ++a;
+        int64_t b = a;
+        while (b < n && !ws(h[b])) ++b;
+        id_off[r] = hdr_off[r] + a;
+        id_len[r] = b - a;
+        uint8_t any = 0;
+        for (int64_t i = 0; i < n; ++i) any |= h[i];
+        if (any & 0x80) ascii = 0;
+    }
+    *all_ascii = ascii;
+    return PFMSCAN_OK;
+}
+
 int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64_t *seq_end, const int64_t *n_letters,
                          int64_t lo, int64_t hi, const uint8_t *lut256, int separator, uint8_t *codes, int64_t *offsets,
                          int n_threads)
@@ -210,8 +235,9 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
     int64_t fixed = 0;                       // bytes of a row that do not depend on the row
     for (int c = 0; c < n_cols; ++c) {
         const pfmscan_tsv_column &col = cols[c];
-        if (col.kind < PFMSCAN_TSV_CONST || col.kind > PFMSCAN_TSV_WINDOW || (!col.data && !(col.kind == PFMSCAN_TSV_CONST && col.width == 0)) ||
-            col.width < 0 || ((col.kind == PFMSCAN_TSV_INDEXED || col.kind == PFMSCAN_TSV_WINDOW) && (!col.aux || !col.blob)))
+        if (col.kind < PFMSCAN_TSV_CONST || col.kind > PFMSCAN_TSV_SPAN || (!col.data && !(col.kind == PFMSCAN_TSV_CONST && col.width == 0)) ||
+            col.width < 0 ||
+            ((col.kind == PFMSCAN_TSV_INDEXED || col.kind == PFMSCAN_TSV_WINDOW || col.kind == PFMSCAN_TSV_SPAN) && (!col.aux || !col.blob)))
             return fail(nullptr, PFMSCAN_E_BADARG, "tsv_format: bad column descriptor");
         switch (col.kind) {
         case PFMSCAN_TSV_CONST: case PFMSCAN_TSV_FIXED: case PFMSCAN_TSV_WINDOW: fixed += col.width; break;
@@ -234,6 +260,9 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                     const int64_t *off = static_cast<const int64_t *>(cols[c].aux);
                     const int64_t v = static_cast<const int64_t *>(cols[c].data)[r];
                     need += (size_t)(off[v + 1] - off[v]);
+                } else if (cols[c].kind == PFMSCAN_TSV_SPAN) {
+                    const int64_t v = static_cast<const int64_t *>(cols[c].data)[r];
+                    need += 2 * (size_t)static_cast<const int64_t *>(cols[c].aux)[2 * v + 1] + 2;      // every byte a doubled quote
                 }
             if (used + need > buf.size()) buf.resize(std::max(buf.size() * 2, used + need));
             char *p = buf.data() + used;
@@ -261,6 +290,26 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                     while (w > 0 && s[w - 1] == 0) --w;              // numpy 'S' items are NUL padded
                     std::memcpy(p, s, (size_t)w);
                     p += w;
+                    break;
+                }
+                case PFMSCAN_TSV_SPAN: {                             // bytes of the caller's buffer, csv.QUOTE_MINIMAL applied here
+                    const int64_t v = static_cast<const int64_t *>(col.data)[r];
+                    const int64_t *span = static_cast<const int64_t *>(col.aux) + 2 * v;
+                    const char *src = static_cast<const char *>(col.blob) + span[0];
+                    const int64_t len = span[1];
+                    bool quote = false;
+                    for (int64_t i = 0; i < len; ++i) quote |= src[i] == '\t' || src[i] == '"' || src[i] == '\n' || src[i] == '\r';
+                    if (!quote) {
+                        std::memcpy(p, src, (size_t)len);
+                        p += len;
+                    } else {
+                        *p++ = '"';
+                        for (int64_t i = 0; i < len; ++i) {
+                            if (src[i] == '"') *p++ = '"';
+                            *p++ = src[i];
+                        }
+                        *p++ = '"';
+                    }
                     break;
                 }
                 default: {                                           // PFMSCAN_TSV_WINDOW

@@ -148,6 +148,11 @@ class FastaSlice(object):
     def descriptions(self):
         return _View(self.parent.headers, self.lo, self.hi)
 
+    def span_tables(self):
+        """(file bytes, id spans [n][2], header spans [n][2]) when the slice sits in ONE plain file whose headers are
+        ASCII -- the writer then copies ids and descriptions from the mapped file itself -- else None."""
+        return self.parent._span_tables(self.lo, self.hi)
+
     def pack_rna(self):
         """(codes uint8 with one separator after every record, offsets, lengths) of the slice, the letters mapped
         as preprocess_seq + pack.encode_rna map them (rnascan.py:186-197, _pwm.c:41-63: case-insensitive, T = U,
@@ -166,6 +171,7 @@ class LazyFasta(object):
         from . import _lib
         self.files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
         self._header_cache = {}
+        self._spans = {}                       # per file: (id spans, header spans) or None (non-ASCII headers)
         self._maps = []                        # per file: the mmap object (bytes slices for the headers)
         self._bufs = []                        # per file: uint8 view of the mapped bytes, or None (compressed)
         self._index = []                       # per file: (hdr_off, hdr_len, seq_off, seq_end, n_letters)
@@ -225,6 +231,22 @@ class LazyFasta(object):
                 rec = _record(self._header(i), [ln.strip().decode("latin-1") for ln in lines])
             out.append(rec)
         return out
+
+    def _span_tables(self, lo, hi):
+        from . import _lib
+        if hi <= lo or (self._parsed and any(i in self._parsed for i in range(lo, hi))):
+            return None
+        fi = int(self._file_of[lo])
+        if int(self._file_of[hi - 1]) != fi:
+            return None
+        if fi not in self._spans:
+            idx = self._index[fi]
+            ids, ascii_ = _lib.fasta_ids(self._bufs[fi], idx[0], idx[1])
+            self._spans[fi] = (ids, np.stack([idx[0], idx[1]], axis=1)) if ascii_ else None
+        if self._spans[fi] is None:
+            return None
+        a, b = int(self._local_of[lo]), int(self._local_of[hi - 1]) + 1
+        return self._bufs[fi], self._spans[fi][0][a:b], self._spans[fi][1][a:b]
 
     def _pack(self, lo, hi, lut):
         from . import _lib

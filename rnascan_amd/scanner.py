@@ -145,9 +145,11 @@ class _RnaBatch(object):
 
     def __init__(self, records):
         packed = records.pack_rna() if hasattr(records, "pack_rna") else None
+        self.spans = None                      # (file bytes, id spans, header spans): strings the writer copies itself
         if packed is not None:
             self.codes, self.offsets, self.lengths = packed
             self.ids, self.descriptions = records.ids, records.descriptions
+            self.spans = records.span_tables()
         else:
             recs = list(records)
             coded = [pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs]
@@ -174,7 +176,15 @@ class _RnaBatch(object):
             out.offsets[1:] = np.cumsum(out.lengths[:-1] + 1)
         out.ids = [self.ids[i] for i in keep]
         out.descriptions = [self.descriptions[i] for i in keep]
+        if self.spans is not None:
+            out.spans = (self.spans[0], self.spans[1][keep], self.spans[2][keep])
         return out
+
+    def id_column(self, rec):
+        return table.Spans(self.spans[0], self.spans[1], rec) if self.spans is not None else table.Indexed(self.ids, rec)
+
+    def description_column(self, rec):
+        return table.Spans(self.spans[0], self.spans[2], rec) if self.spans is not None else table.Indexed(self.descriptions, rec)
 
 
 def _finish(tables, order, sort_keys, columns):
@@ -205,7 +215,7 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
         order = pack.RNA_LETTERS                               # sorted(alphabet.letters), matrix.py:57
         batch = _RnaBatch(records)
         stream = pack.Stream(batch.codes, None, batch.offsets, batch.lengths)   # packed (and staged on the device) once
-        ids, descriptions = batch.ids, batch.descriptions
+        id_column, description_column = batch.id_column, batch.description_column
 
         def fragments(pos, rec, start, m):
             return table.Windows(stream.codes, pos, m, order)
@@ -216,13 +226,19 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
         stream = pack.pack([pack.encode_letters(s, order) for s in seqs])       # _py_calculate upper-cases, matrix.py:31
         ids, descriptions = [r.id for r in recs], [r.description for r in recs]
 
+        def id_column(rec):
+            return table.Indexed(ids, rec)
+
+        def description_column(rec):
+            return table.Indexed(descriptions, rec)
+
         def fragments(pos, rec, start, m):
             return [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
     tables = []
 
     def rows(motif_ids, m, pos, mo, logodds):
         rec, start = stream.locate(pos)
-        return {"_rec": rec, "Sequence_ID": table.Indexed(ids, rec), "Description": table.Indexed(descriptions, rec),
+        return {"_rec": rec, "Sequence_ID": id_column(rec), "Description": description_column(rec),
                 "Motif_ID": motif_ids[0] if mo is None else table.Indexed(motif_ids, mo),
                 "Start": start + 1, "End": start + m, "Sequence": fragments(pos, rec, start, m), "LogOdds": logodds}
 
@@ -459,8 +475,8 @@ def _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, st
             lo_seq = np.round(sq, 3)
             tables.append({
                 "_rec": rec,
-                "Sequence_ID": table.Indexed(batch.ids, rec),
-                "Description.Seq": table.Indexed(batch.descriptions, rec),
+                "Sequence_ID": batch.id_column(rec),
+                "Description.Seq": batch.description_column(rec),
                 "Motif_ID.Seq": table.Indexed([a for a, _ in group], mo), "Start": start + 1, "End": start + m,
                 "Sequence.Seq": table.Windows(stream.codes, pos, m, pack.RNA_LETTERS),
                 "LogOdds.Seq": lo_seq, "Description.Struct": "",

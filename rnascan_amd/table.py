@@ -34,6 +34,26 @@ class Indexed(object):
         return vals[inv]
 
 
+class Spans(object):
+    """A string column given as byte spans of a buffer: row r holds ``buffer[off:off + n]`` for (off, n) =
+    ``spans[index[r]]`` -- ids and headers straight from the mapped FASTA file (ASCII), never made into Python strings
+    on the streaming path; csv quoting is applied by the native formatter."""
+
+    def __init__(self, buffer, spans, index):
+        self.buffer = buffer
+        self.spans = np.ascontiguousarray(spans, dtype=np.int64)
+        self.index = np.asarray(index, dtype=np.int64)
+
+    def __len__(self):
+        return self.index.shape[0]
+
+    def materialize(self):
+        used, inv = np.unique(self.index, return_inverse=True)
+        vals = np.empty(used.size, dtype=object)
+        vals[:] = [self.buffer[o:o + n].tobytes().decode("ascii") for o, n in self.spans[used].tolist()]
+        return vals[inv]
+
+
 class Windows(object):
     """The ``Sequence`` column given as stream positions into a code array: row r holds the ``m`` letters
     ``letters[codes[pos[r] + j]]`` (rnascan.py:272 slices the record string per hit)."""
@@ -56,7 +76,7 @@ class Windows(object):
 
 
 def column_length(col):
-    if isinstance(col, (Indexed, Windows)):
+    if isinstance(col, (Indexed, Windows, Spans)):
         return len(col)
     if isinstance(col, str) or np.ndim(col) == 0:
         return None
@@ -71,7 +91,7 @@ def to_frame(columns, order=None):
     data = {}
     for c in order:
         col = columns[c]
-        if isinstance(col, (Indexed, Windows)):
+        if isinstance(col, (Indexed, Windows, Spans)):
             col = col.materialize()
         elif column_length(col) is None:
             col = np.full(n, col, dtype=object if isinstance(col, str) else None)
@@ -109,6 +129,10 @@ def _descriptor(col, n):
         used, inv = np.unique(col.index, return_inverse=True)
         off, blob = _blob([col.values[i] for i in used.tolist()])
         return (_lib.TSV_INDEXED, inv.astype(np.int64), off, blob, 0)
+    if isinstance(col, Spans):
+        if len(col) != n:
+            raise ValueError("column length mismatch")
+        return (_lib.TSV_SPAN, col.index, col.spans, col.buffer, 0)
     if isinstance(col, Windows):
         if len(col) != n:
             raise ValueError("column length mismatch")
@@ -140,7 +164,7 @@ def _descriptor(col, n):
 
 class TsvWriter(object):
     """write_chunk(columns) appends rows; columns is an ordered mapping name -> array | list | scalar |
-    Indexed | Windows (a DataFrame's columns work as arrays)."""
+    Indexed | Spans | Windows (a DataFrame's columns work as arrays)."""
 
     def __init__(self, out, columns, match_id=True):
         self.out = out

@@ -197,3 +197,28 @@ def test_background_counts_natively_equal_the_record_loop(tmp_path):
     total = sum(want.values()) + 4
     bg = fasta.compute_background(path, fasta.RNA, verbose=False)
     assert bg == {l: (want[l] + 1.0) / total for l in fasta.RNA}
+
+
+def test_ids_and_headers_as_spans_of_the_mapped_file(tmp_path):
+    data = (b">r1 first\trecord \"q\"\nACGU\n>  \x1c r2\x1dmore  words \nGG\n>\nA\n>r4\r\nAC\n>we\"ird\nUU\n")
+    path = _write(tmp_path, "s.fa", data)
+    recs = list(fasta.parse_sequences(path))
+    lazy = fasta.LazyFasta(path)
+    buf, id_spans, hdr_spans = lazy[0:len(lazy)].span_tables()
+    assert [buf[o:o + n].tobytes().decode() for o, n in id_spans.tolist()] == [r.id for r in recs]
+    assert [buf[o:o + n].tobytes().decode() for o, n in hdr_spans.tolist()] == [r.description for r in recs]
+    sub = lazy[1:4].span_tables()
+    assert [buf[o:o + n].tobytes().decode() for o, n in sub[1].tolist()] == [r.id for r in recs[1:4]]
+    # the writer quotes span fields like to_csv does
+    idx = np.array([0, 0, 1, 2, 3, 4, 4])
+    cols = {"Sequence_ID": table.Spans(buf, id_spans, idx), "Description": table.Spans(buf, hdr_spans, idx), "Start": np.arange(7)}
+    df = table.to_frame(cols)
+    assert df["Sequence_ID"].tolist() == [recs[i].id for i in idx] and df["Description"].tolist() == [recs[i].description for i in idx]
+    out = io.StringIO()
+    table.TsvWriter(out, list(cols), match_id=False).write_chunk(cols)
+    assert out.getvalue() == df.to_csv(sep="\t", index=False)
+    # a header with a non-ASCII byte: no spans, the strings are decoded in Python as before
+    path2 = _write(tmp_path, "n.fa", NASTY)
+    assert fasta.LazyFasta(path2)[0:3].span_tables() is None
+    two = fasta.LazyFasta([path, path])
+    assert two[3:7].span_tables() is None and two[5:8].span_tables() is not None        # a slice across two files has no one buffer
