@@ -268,7 +268,8 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
  * line without '>' and without trailing \r \n, the letters are every later line stripped of ASCII whitespace at
  * both ends with embedded blanks removed; bytes before the first header are ignored.
  *
- * pfmscan_fasta_index: one pass over `buf`.  capacity == 0 (arrays may be NULL): only counts the records and
+ * pfmscan_fasta_index: one pass over `buf` (cut into one piece per thread at line starts, stitched afterwards).
+ *   capacity == 0 (arrays may be NULL): only counts the records and
  *   returns PFMSCAN_E_CAPACITY with *n_records set (PFMSCAN_OK when there are none).  Otherwise fills, per record,
  *   hdr_off / hdr_len (header bytes), seq_off / seq_end (byte range of its sequence lines), n_letters.
  * pfmscan_fasta_encode: records [lo, hi) -> codes[sum(n_letters + 1)]: lut256[byte] per letter, `separator`
@@ -276,7 +277,7 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
  *   as many as the host offers, at most 16. */
 int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t *hdr_off,
                         int64_t *hdr_len, int64_t *seq_off, int64_t *seq_end, int64_t *n_letters,
-                        int64_t *n_records);
+                        int64_t *n_records, int n_threads);
  /* pfmscan_fasta_ids: the id of every record = the first whitespace-separated word of its header
   *   (id_off, id_len: byte span in buf); *all_ascii = 0 when some header holds a byte >= 0x80 (the caller then
   *   decodes the headers itself). */

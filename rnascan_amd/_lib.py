@@ -121,7 +121,7 @@ def load():
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
-    L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), i32]
@@ -158,20 +158,21 @@ def _raise(L, ctx, rc, n_hits=None):
 # ---------------------------------------------------------------------------
 # host ingest / output (no device, no context)
 # ---------------------------------------------------------------------------
-def fasta_index(buf):
+def fasta_index(buf, threads=0):
     """uint8 array of FASTA bytes -> (hdr_off, hdr_len, seq_off, seq_end, n_letters), int64 [n_records] each."""
     L = load()
     buf = np.asarray(buf)
     n = ctypes.c_int64(0)
-    rc = L.pfmscan_fasta_index(_ptr(buf), buf.size, 0, None, None, None, None, None, ctypes.byref(n))
-    if rc not in (OK, E_CAPACITY):
-        _raise(L, None, rc)
-    cols = [np.empty(n.value, dtype=np.int64) for _ in range(5)]
-    if n.value:
-        rc = L.pfmscan_fasta_index(_ptr(buf), buf.size, n.value, *[_ptr(c) for c in cols], ctypes.byref(n))
+    cap = max(1024, buf.size // 64)            # untouched pages of an over-sized np.empty cost nothing
+    while True:
+        cols = [np.empty(cap, dtype=np.int64) for _ in range(5)]
+        rc = L.pfmscan_fasta_index(_ptr(buf), buf.size, cap, *[_ptr(c) for c in cols], ctypes.byref(n), int(threads))
+        if rc == E_CAPACITY and n.value > cap:
+            cap = n.value                      # a file of very short records: once more with the exact count
+            continue
         if rc != OK:
             _raise(L, None, rc)
-    return tuple(cols)
+        return tuple(c[:n.value] for c in cols)
 
 
 def fasta_ids(buf, hdr_off, hdr_len):
@@ -204,7 +205,7 @@ def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, t
 
 
 def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None):
-    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes; returns the rows as a bytearray."""
+    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes; returns the rows as a memoryview of bytes."""
     L = load()
     keep, desc = [], (TsvColumn * len(columns))()
     for i, (kind, data, aux, blob, width) in enumerate(columns):
@@ -224,18 +225,14 @@ def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None):
     cap = int(estimate) if estimate else max(1 << 16, n_rows * 96)
     n = ctypes.c_int64(0)
     while True:
-        out = bytearray(cap)
-        view = (ctypes.c_char * cap).from_buffer(out)
-        rc = L.pfmscan_tsv_format(desc, len(columns), int(n_rows), int(first_match_id), ctypes.addressof(view), cap, ctypes.byref(n),
-                                  int(threads))
-        del view
+        out = np.empty(cap, dtype=np.uint8)
+        rc = L.pfmscan_tsv_format(desc, len(columns), int(n_rows), int(first_match_id), _ptr(out), cap, ctypes.byref(n), int(threads))
         if rc == E_CAPACITY and n.value > cap:
             cap = n.value
             continue
         if rc != OK:
             _raise(L, None, rc)
-        del out[n.value:]
-        return out
+        return memoryview(out)[:n.value]
 
 
 class Context(object):

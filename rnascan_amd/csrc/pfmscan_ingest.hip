@@ -8,6 +8,7 @@
 #include <charconv>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -31,8 +32,12 @@ inline void strip(const uint8_t *buf, int64_t &a, int64_t &b)
 inline int64_t count_letters(const uint8_t *buf, int64_t a, int64_t b)
 {
     strip(buf, a, b);
-    int64_t spaces = 0;
-    for (int64_t i = a; i < b; ++i) spaces += buf[i] == ' ';
+    int64_t spaces = 0;                                             // embedded blanks are rare: let memchr look for them
+    const uint8_t *q = buf + a, *const end = buf + b;
+    while (q < end && (q = static_cast<const uint8_t *>(std::memchr(q, ' ', (size_t)(end - q)))) != nullptr) {
+        ++spaces;
+        ++q;
+    }
     return (b - a) - spaces;
 }
 
@@ -115,44 +120,142 @@ inline char *put_int(char *p, int64_t v) { return std::to_chars(p, p + 24, v).pt
 
 }  // namespace
 
+namespace {
+
+// one record's sequence lines -> out[0 .. want] (want letters + the separator); nonzero when the bytes hold a different
+// number of letters than the index says (never writes past out[want])
+int encode_record(const uint8_t *__restrict buf, int64_t pos, const int64_t stop, const int64_t want, const uint8_t *__restrict lut,
+                  const uint8_t separator, uint8_t *__restrict out)
+{
+    int64_t k = 0;
+    int wrong = 0;
+    while (pos < stop) {
+        const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + pos, '\n', (size_t)(stop - pos)));
+        int64_t e = nl ? nl - buf : stop;
+        const int64_t next = nl ? e + 1 : stop;
+        int64_t s = pos;
+        strip(buf, s, e);
+        if (k + (e - s) > want) {                                  // index and bytes disagree
+            for (; s < e; ++s)
+                if (buf[s] != ' ') {
+                    if (k < want)
+                        out[k++] = lut[buf[s]];
+                    else
+                        wrong = 1;
+                }
+        } else if (!std::memchr(buf + s, ' ', (size_t)(e - s))) {  // the usual line: no blanks
+            const uint8_t *__restrict src = buf + s;
+            uint8_t *__restrict dst = out + k;
+            const int64_t n = e - s;
+            for (int64_t i = 0; i < n; ++i) dst[i] = lut[src[i]];
+            k += n;
+        } else {
+            for (; s < e; ++s)
+                if (buf[s] != ' ') out[k++] = lut[buf[s]];
+        }
+        pos = next;
+    }
+    if (k != want) wrong = 1;
+    for (; k < want; ++k) out[k] = separator;
+    out[want] = separator;
+    return wrong;
+}
+
+struct FastaRec {
+    int64_t hdr_off, hdr_len, seq_off, seq_end, letters;
+};
+
+// records whose header line STARTS in [from, to) (both line starts); `lead` = letters of the lines before the first
+// such header (they belong to a record that began in an earlier piece)
+void index_piece(const uint8_t *buf, int64_t n, int64_t from, int64_t to, bool count_only, std::vector<FastaRec> &out,
+                 int64_t &lead, int64_t &first_hdr, int64_t &count)
+{
+    int64_t pos = from, letters = 0;
+    bool open = false;
+    lead = 0;
+    first_hdr = -1;
+    count = 0;
+    while (pos < to) {
+        const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + pos, '\n', (size_t)(n - pos)));
+        const int64_t e = nl ? nl - buf : n, next = nl ? e + 1 : n;
+        if (buf[pos] == '>') {
+            if (first_hdr < 0) first_hdr = pos;
+            ++count;
+            if (!count_only) {
+                if (open) {
+                    out.back().seq_end = pos;
+                    out.back().letters = letters;
+                } else {
+                    lead = letters;
+                }
+                int64_t he = e;
+                while (he > pos + 1 && (buf[he - 1] == '\r' || buf[he - 1] == '\n')) --he;    // rstrip("\r\n")
+                out.push_back({pos + 1, he - (pos + 1), next, next, 0});
+            }
+            open = true;
+            letters = 0;
+        } else if (!count_only) {
+            letters += count_letters(buf, pos, e);
+        }
+        pos = next;
+    }
+    if (!count_only) {
+        if (open) {
+            out.back().seq_end = to;
+            out.back().letters = letters;
+        } else {
+            lead = letters;
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t *hdr_off, int64_t *hdr_len,
-                        int64_t *seq_off, int64_t *seq_end, int64_t *n_letters, int64_t *n_records)
+                        int64_t *seq_off, int64_t *seq_end, int64_t *n_letters, int64_t *n_records, int n_threads)
 {
     if ((!buf && n > 0) || n < 0 || capacity < 0 || !n_records) return fail(nullptr, PFMSCAN_E_BADARG, "fasta_index: bad argument");
     const bool fill = capacity > 0;
     if (fill && (!hdr_off || !hdr_len || !seq_off || !seq_end || !n_letters))
         return fail(nullptr, PFMSCAN_E_BADARG, "fasta_index: NULL output array");
-    int64_t rec = -1, letters = 0, pos = 0;
-    while (pos < n) {
-        const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + pos, '\n', (size_t)(n - pos)));
-        const int64_t e = nl ? nl - buf : n, next = nl ? e + 1 : n;
-        if (buf[pos] == '>') {
-            if (rec >= 0 && rec < capacity) {
-                seq_end[rec] = pos;
-                n_letters[rec] = letters;
-            }
-            ++rec;
-            letters = 0;
-            if (rec < capacity) {
-                int64_t he = e;
-                while (he > pos + 1 && (buf[he - 1] == '\r' || buf[he - 1] == '\n')) --he;    // rstrip("\r\n")
-                hdr_off[rec] = pos + 1;
-                hdr_len[rec] = he - (pos + 1);
-                seq_off[rec] = next;
-            }
-        } else if (rec >= 0 && fill) {
-            letters += count_letters(buf, pos, e);
+    // pieces of the buffer that start at a line start, one per thread
+    const int threads = n_threads > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n)) : pick_threads(0, n >> 20);
+    std::vector<int64_t> cut((size_t)threads + 1, n);
+    cut[0] = 0;
+    for (int t = 1; t < threads; ++t) {
+        const int64_t guess = std::max(cut[(size_t)t - 1], n * t / threads);
+        const uint8_t *nl = guess < n ? static_cast<const uint8_t *>(std::memchr(buf + guess, '\n', (size_t)(n - guess))) : nullptr;
+        cut[(size_t)t] = nl ? (nl - buf) + 1 : n;
+    }
+    std::vector<std::vector<FastaRec>> recs((size_t)threads);
+    std::vector<int64_t> lead((size_t)threads, 0), first((size_t)threads, -1), count((size_t)threads, 0);
+    parallel_ranges(threads, threads, [&](int, int64_t a, int64_t b) {
+        for (int64_t t = a; t < b; ++t)
+            index_piece(buf, n, cut[(size_t)t], cut[(size_t)t + 1], !fill, recs[(size_t)t], lead[(size_t)t], first[(size_t)t],
+                        count[(size_t)t]);
+    });
+    int64_t total = 0;
+    for (int64_t c : count) total += c;
+    *n_records = total;
+    if (total > capacity) return fill ? fail(nullptr, PFMSCAN_E_CAPACITY, "fasta_index: more records than capacity") : PFMSCAN_E_CAPACITY;
+    // stitch: the lines a piece holds before its first header continue the last record of the pieces before it
+    int64_t k = 0, last = -1;
+    for (int t = 0; t < threads; ++t) {
+        if (last >= 0) {
+            n_letters[last] += lead[(size_t)t];
+            seq_end[last] = first[(size_t)t] >= 0 ? first[(size_t)t] : cut[(size_t)t + 1];
         }
-        pos = next;
+        for (const FastaRec &r : recs[(size_t)t]) {
+            hdr_off[k] = r.hdr_off;
+            hdr_len[k] = r.hdr_len;
+            seq_off[k] = r.seq_off;
+            seq_end[k] = r.seq_end;
+            n_letters[k] = r.letters;
+            last = k++;
+        }
     }
-    if (rec >= 0 && rec < capacity) {
-        seq_end[rec] = n;
-        n_letters[rec] = letters;
-    }
-    *n_records = rec + 1;
-    if (rec + 1 > capacity) return fill ? fail(nullptr, PFMSCAN_E_CAPACITY, "fasta_index: more records than capacity") : PFMSCAN_E_CAPACITY;
     return PFMSCAN_OK;
 }
 
@@ -195,32 +298,10 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
     }
     std::vector<int> bad((size_t)pick_threads(n_threads, nrec), 0);
     parallel_ranges(nrec, (int)bad.size(), [&](int t, int64_t a, int64_t b) {
-        for (int64_t i = a; i < b; ++i) {
-            uint8_t *out = codes + offsets[i];
-            int64_t k = 0, pos = seq_off[lo + i];
-            const int64_t stop = seq_end[lo + i], want = n_letters[lo + i];
-            while (pos < stop) {
-                const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + pos, '\n', (size_t)(stop - pos)));
-                int64_t e = nl ? nl - buf : stop;
-                const int64_t next = nl ? e + 1 : stop;
-                int64_t s = pos;
-                strip(buf, s, e);
-                if (k + (e - s) > want) {                              // index and bytes disagree: never write past the record
-                    int64_t room = want - k;
-                    for (; s < e && room > 0; ++s)
-                        if (buf[s] != ' ') out[k++] = lut256[buf[s]], --room;
-                    for (; s < e; ++s)
-                        if (buf[s] != ' ') bad[(size_t)t] = 1;
-                } else {
-                    for (; s < e; ++s)
-                        if (buf[s] != ' ') out[k++] = lut256[buf[s]];
-                }
-                pos = next;
-            }
-            if (k != want) bad[(size_t)t] = 1;
-            for (; k < want; ++k) out[k] = (uint8_t)separator;
-            out[want] = (uint8_t)separator;
-        }
+        int wrong = 0;
+        for (int64_t i = a; i < b; ++i)
+            wrong |= encode_record(buf, seq_off[lo + i], seq_end[lo + i], n_letters[lo + i], lut256, (uint8_t)separator, codes + offsets[i]);
+        bad[(size_t)t] = wrong;
     });
     for (int v : bad)
         if (v) return fail(nullptr, PFMSCAN_E_BADARG, "fasta_encode: the index does not describe these bytes (file changed since it was indexed?)");
@@ -248,11 +329,21 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
     }
     fixed += n_cols + (first_match_id >= 0 ? 21 : 0);
     const int threads = pick_threads(n_threads, (n_rows + 4095) / 4096);
-    std::vector<std::vector<char>> part((size_t)threads);
+    struct Part {                                    // a thread's rows: raw storage, never zero-filled
+        char *p = nullptr;
+        size_t cap = 0, used = 0;
+        bool oom = false;
+        ~Part() { std::free(p); }
+    };
+    std::vector<Part> part((size_t)threads);
     parallel_ranges(n_rows, threads, [&](int t, int64_t a, int64_t b) {
-        std::vector<char> &buf = part[(size_t)t];
-        buf.resize((size_t)std::max<int64_t>(1 << 16, (b - a) * (fixed + 16)));
-        size_t used = 0;
+        Part &buf = part[(size_t)t];
+        buf.cap = (size_t)std::max<int64_t>(1 << 16, (b - a) * (fixed + 16));
+        buf.p = static_cast<char *>(std::malloc(buf.cap));
+        if (!buf.p) {
+            buf.oom = true;
+            return;
+        }
         for (int64_t r = a; r < b; ++r) {
             size_t need = (size_t)fixed;
             for (int c = 0; c < n_cols; ++c)
@@ -264,8 +355,17 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                     const int64_t v = static_cast<const int64_t *>(cols[c].data)[r];
                     need += 2 * (size_t)static_cast<const int64_t *>(cols[c].aux)[2 * v + 1] + 2;      // every byte a doubled quote
                 }
-            if (used + need > buf.size()) buf.resize(std::max(buf.size() * 2, used + need));
-            char *p = buf.data() + used;
+            if (buf.used + need > buf.cap) {
+                const size_t cap = std::max(buf.cap * 2, buf.used + need);
+                char *q = static_cast<char *>(std::realloc(buf.p, cap));
+                if (!q) {
+                    buf.oom = true;
+                    return;
+                }
+                buf.p = q;
+                buf.cap = cap;
+            }
+            char *p = buf.p + buf.used;
             for (int c = 0; c < n_cols; ++c) {
                 const pfmscan_tsv_column &col = cols[c];
                 if (c) *p++ = '\t';
@@ -325,19 +425,21 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                 p = put_int(p, first_match_id + r);
             }
             *p++ = '\n';
-            used = (size_t)(p - buf.data());
+            buf.used = (size_t)(p - buf.p);
         }
-        buf.resize(used);
     });
     int64_t total = 0;
-    for (auto &b : part) total += (int64_t)b.size();
+    for (auto &b : part) {
+        if (b.oom) return fail(nullptr, PFMSCAN_E_OOM, "tsv_format: out of host memory");
+        total += (int64_t)b.used;
+    }
     *n_bytes = total;
     if (total > capacity) return fail(nullptr, PFMSCAN_E_CAPACITY, "tsv_format: output buffer too small");
     std::vector<int64_t> at((size_t)threads, 0);
-    for (int t = 1; t < threads; ++t) at[(size_t)t] = at[(size_t)t - 1] + (int64_t)part[(size_t)t - 1].size();
+    for (int t = 1; t < threads; ++t) at[(size_t)t] = at[(size_t)t - 1] + (int64_t)part[(size_t)t - 1].used;
     parallel_ranges(threads, threads, [&](int, int64_t a, int64_t b) {
         for (int64_t t = a; t < b; ++t)
-            if (!part[(size_t)t].empty()) std::memcpy(out + at[(size_t)t], part[(size_t)t].data(), part[(size_t)t].size());
+            if (part[(size_t)t].used) std::memcpy(out + at[(size_t)t], part[(size_t)t].p, part[(size_t)t].used);
     });
     return PFMSCAN_OK;
 }

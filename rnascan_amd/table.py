@@ -185,7 +185,7 @@ class TsvWriter(object):
             self.out.flush()
             raw.write(text)                      # a text stream over a byte stream: no decode / re-encode of the rows
         else:
-            self.out.write(text.decode("utf-8"))
+            self.out.write(bytes(text).decode("utf-8"))
         self.rows += n
 
 

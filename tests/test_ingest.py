@@ -75,6 +75,9 @@ def test_native_fasta_property(tmp_path_factory, lines, eol, tail, threads):
     recs = list(fasta.parse_sequences(path))
     buf = np.frombuffer(data, dtype=np.uint8)
     ix = _lib.fasta_index(buf)
+    for pieces in (2, 3, 7):                             # the index cut into pieces at line starts and stitched
+        again = _lib.fasta_index(buf, threads=pieces)
+        assert all(np.array_equal(x, y) for x, y in zip(ix, again))
     assert ix[0].size == len(recs)
     assert ix[4].tolist() == [len(r.seq) for r in recs]
     assert [data[o:o + n].decode("latin-1") for o, n in zip(ix[0].tolist(), ix[1].tolist())] == [r.description for r in recs]
@@ -103,7 +106,7 @@ def test_lazy_fasta_over_several_files_and_compressed_input(tmp_path):
 
 def test_fasta_index_argument_errors():
     L = _lib.load()
-    assert L.pfmscan_fasta_index(None, 5, 0, None, None, None, None, None, None) == _lib.E_BADARG
+    assert L.pfmscan_fasta_index(None, 5, 0, None, None, None, None, None, None, 0) == _lib.E_BADARG
     buf = np.frombuffer(b">a\nAC\n>b\nGU\n", dtype=np.uint8)
     ix = _lib.fasta_index(buf)
     wrong = ix[4].copy()

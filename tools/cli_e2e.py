@@ -56,9 +56,17 @@ for name, argv in runs:
     nrec = RBIG if name.startswith("big") else R
     path = os.path.join(d, "out.tsv")
     with open(path, "w", encoding="utf-8", newline="") as out:
+        prof = None
+        if os.environ.get("CLI_E2E_PROFILE") and name.startswith("big"):
+            import cProfile, pstats
+            prof = cProfile.Profile()
+            prof.enable()
         t = time.time()
         cli.main(argv, out=out)
         dt = time.time() - t
+        if prof is not None:
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stdout).sort_stats("tottime").print_stats(12)
     rows = sum(1 for _ in open(path, "rb")) - 1
     print("%-28s %.2f s   %d rows   %.3g windows/s   %.1f MB of table" % (name, dt, rows, nrec * (L - 17) / dt,
                                                                          os.path.getsize(path) / 1e6))
