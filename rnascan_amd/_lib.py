@@ -204,8 +204,10 @@ def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, t
     return codes, offsets
 
 
-def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None):
-    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes; returns the rows as a memoryview of bytes."""
+def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None, scratch=None):
+    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes; returns the rows as a memoryview of bytes.
+    ``scratch``: a one-element list holding a reusable uint8 array (grown here when too small) -- a writer that formats
+    chunk after chunk then touches fresh pages only once."""
     L = load()
     keep, desc = [], (TsvColumn * len(columns))()
     for i, (kind, data, aux, blob, width) in enumerate(columns):
@@ -225,7 +227,13 @@ def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None):
     cap = int(estimate) if estimate else max(1 << 16, n_rows * 96)
     n = ctypes.c_int64(0)
     while True:
-        out = np.empty(cap, dtype=np.uint8)
+        if scratch is not None and scratch[0] is not None and scratch[0].size >= cap:
+            out = scratch[0]
+            cap = out.size
+        else:
+            out = np.empty(cap, dtype=np.uint8)
+            if scratch is not None:
+                scratch[0] = out
         rc = L.pfmscan_tsv_format(desc, len(columns), int(n_rows), int(first_match_id), _ptr(out), cap, ctypes.byref(n), int(threads))
         if rc == E_CAPACITY and n.value > cap:
             cap = n.value

@@ -160,9 +160,11 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         return df
     fasta.eprint("Scanning sequences ")
     recs = fasta.LazyFasta(source)                     # index only: a rank / a batch reads just its own records
+    # nucleotide letters only: a position is one byte on the device and four in the score array, so a launch takes 8 x the
+    # positions a profile batch may hold
     df = shard.scan_sharded(recs, recs.lengths,
                             lambda part: scanner.scan_records(engine, part, pssm, letters, args.minscore, compact),
-                            rank, world, dist, sink=sink)
+                            rank, world, dist, max_positions=(8 if fasta.is_rna_letters(letters) else 1) * shard.batch_positions(), sink=sink)
     fasta.eprint("Processed %d sequences" % len(recs))
     return df
 

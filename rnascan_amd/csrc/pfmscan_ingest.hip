@@ -328,7 +328,7 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
         }
     }
     fixed += n_cols + (first_match_id >= 0 ? 21 : 0);
-    const int threads = pick_threads(n_threads, (n_rows + 4095) / 4096);
+    const int threads = pick_threads(n_threads, (n_rows + 32767) / 32768);      // a thread is worth starting for ~32k rows
     struct Part {                                    // a thread's rows: raw storage, never zero-filled
         char *p = nullptr;
         size_t cap = 0, used = 0;

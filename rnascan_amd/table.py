@@ -171,6 +171,7 @@ class TsvWriter(object):
         self.columns = list(columns)
         self.match_id = match_id
         self.rows = 0
+        self._scratch = [None]                   # row buffer reused from chunk to chunk
         out.write("\t".join([_quote(c) for c in self.columns] + (["Match_ID"] if match_id else [])) + "\n")
 
     def write_chunk(self, data, n=None):
@@ -179,7 +180,7 @@ class TsvWriter(object):
         if n == 0:
             return
         desc = [_descriptor(data[c], n) for c in self.columns]
-        text = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1)
+        text = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1, scratch=self._scratch)
         raw = getattr(self.out, "buffer", None)
         if raw is not None and getattr(self.out, "encoding", "utf-8").lower().replace("-", "") == "utf8":
             self.out.flush()
