@@ -303,7 +303,10 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
  *            bytes of blob (ids / headers straight from the mapped FASTA), csv-quoted here when they hold a tab, a
  *            double quote or a line break
  * first_match_id >= 0 appends a last column counting up from it.  Every row ends in '\n'; no header line.
- * PFMSCAN_E_CAPACITY: *n_bytes holds the size that suffices, nothing was written. */
+ * The rows are written by up to PFMSCAN_TSV_MAX_PIECES threads, each into its own slice of `out` (no intermediate
+ * buffer, no copy): afterwards piece k is out[pieces[2k] .. pieces[2k] + pieces[2k + 1]) and the table is the
+ * pieces in order, k = 0 .. *n_pieces - 1.  `capacity` must cover n_rows x the longest possible row; *need holds that
+ * size (PFMSCAN_E_CAPACITY when capacity is smaller: nothing was written). */
 #define PFMSCAN_TSV_CONST   0
 #define PFMSCAN_TSV_I64     1
 #define PFMSCAN_TSV_F32     2
@@ -312,6 +315,7 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
 #define PFMSCAN_TSV_FIXED   5
 #define PFMSCAN_TSV_WINDOW  6
 #define PFMSCAN_TSV_SPAN    7
+#define PFMSCAN_TSV_MAX_PIECES 16
 typedef struct pfmscan_tsv_column {
     int32_t kind;
     int32_t reserved;
@@ -321,7 +325,8 @@ typedef struct pfmscan_tsv_column {
     int64_t width;
 } pfmscan_tsv_column;
 int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_rows,
-                       int64_t first_match_id, char *out, int64_t capacity, int64_t *n_bytes,
+                       int64_t first_match_id, char *out, int64_t capacity, int64_t *need,
+                       int64_t *pieces /* [2 * PFMSCAN_TSV_MAX_PIECES] */, int *n_pieces,
                        int n_threads);
 
 /* ---- measurement helper ------------------------------------------------------

@@ -124,7 +124,7 @@ def load():
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
-    L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), i32]
+    L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i32), i32]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
                         "pfmscan_staged_positions"):
@@ -204,10 +204,14 @@ def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, t
     return codes, offsets
 
 
+TSV_MAX_PIECES = 16
+
+
 def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None, scratch=None):
-    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes; returns the rows as a memoryview of bytes.
+    """columns: list of (kind, data, aux, blob, width) with numpy arrays / bytes.  Returns the rows as a list of
+    memoryviews (one per formatting thread) whose concatenation is the table.
     ``scratch``: a one-element list holding a reusable uint8 array (grown here when too small) -- a writer that formats
-    chunk after chunk then touches fresh pages only once."""
+    chunk after chunk then touches fresh pages only once; the views point into it until the next call."""
     L = load()
     keep, desc = [], (TsvColumn * len(columns))()
     for i, (kind, data, aux, blob, width) in enumerate(columns):
@@ -224,8 +228,9 @@ def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None, scr
                 keep.append(arr)
                 ptrs.append(arr.ctypes.data)
         desc[i] = TsvColumn(int(kind), 0, ptrs[0], ptrs[1], ptrs[2], int(width))
-    cap = int(estimate) if estimate else max(1 << 16, n_rows * 96)
-    n = ctypes.c_int64(0)
+    cap = int(estimate) if estimate else max(1 << 16, n_rows * 128)
+    need, n_pieces = ctypes.c_int64(0), ctypes.c_int(0)
+    pieces = np.zeros(2 * TSV_MAX_PIECES, dtype=np.int64)
     while True:
         if scratch is not None and scratch[0] is not None and scratch[0].size >= cap:
             out = scratch[0]
@@ -234,13 +239,15 @@ def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None, scr
             out = np.empty(cap, dtype=np.uint8)
             if scratch is not None:
                 scratch[0] = out
-        rc = L.pfmscan_tsv_format(desc, len(columns), int(n_rows), int(first_match_id), _ptr(out), cap, ctypes.byref(n), int(threads))
-        if rc == E_CAPACITY and n.value > cap:
-            cap = n.value
+        rc = L.pfmscan_tsv_format(desc, len(columns), int(n_rows), int(first_match_id), _ptr(out), cap, ctypes.byref(need),
+                                  _ptr(pieces), ctypes.byref(n_pieces), int(threads))
+        if rc == E_CAPACITY and need.value > cap:
+            cap = need.value
             continue
         if rc != OK:
             _raise(L, None, rc)
-        return memoryview(out)[:n.value]
+        view = memoryview(out)
+        return [view[int(pieces[2 * k]):int(pieces[2 * k] + pieces[2 * k + 1])] for k in range(n_pieces.value)]
 
 
 class Context(object):

@@ -309,11 +309,15 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
 }
 
 int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_rows, int64_t first_match_id, char *out,
-                       int64_t capacity, int64_t *n_bytes, int n_threads)
+                       int64_t capacity, int64_t *need, int64_t *pieces, int *n_pieces, int n_threads)
 {
-    if (!cols || n_cols <= 0 || n_rows < 0 || !n_bytes || capacity < 0 || (!out && capacity > 0))
+    if (!cols || n_cols <= 0 || n_rows < 0 || !need || !pieces || !n_pieces || capacity < 0 || (!out && capacity > 0))
         return fail(nullptr, PFMSCAN_E_BADARG, "tsv_format: bad argument");
-    int64_t fixed = 0;                       // bytes of a row that do not depend on the row
+    const int threads = pick_threads(std::min(n_threads > 0 ? n_threads : PFMSCAN_TSV_MAX_PIECES, PFMSCAN_TSV_MAX_PIECES),
+                                     (n_rows + 16383) / 16384);                    // a thread is worth starting for ~16k rows
+    // the most bytes a row can take: every thread then owns a slice of `out` it cannot overrun
+    int64_t bound = n_cols + (first_match_id >= 0 ? 21 : 0);
+    std::vector<int64_t> longest((size_t)n_cols, 0);
     for (int c = 0; c < n_cols; ++c) {
         const pfmscan_tsv_column &col = cols[c];
         if (col.kind < PFMSCAN_TSV_CONST || col.kind > PFMSCAN_TSV_SPAN || (!col.data && !(col.kind == PFMSCAN_TSV_CONST && col.width == 0)) ||
@@ -321,51 +325,34 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
             ((col.kind == PFMSCAN_TSV_INDEXED || col.kind == PFMSCAN_TSV_WINDOW || col.kind == PFMSCAN_TSV_SPAN) && (!col.aux || !col.blob)))
             return fail(nullptr, PFMSCAN_E_BADARG, "tsv_format: bad column descriptor");
         switch (col.kind) {
-        case PFMSCAN_TSV_CONST: case PFMSCAN_TSV_FIXED: case PFMSCAN_TSV_WINDOW: fixed += col.width; break;
-        case PFMSCAN_TSV_I64: fixed += 21; break;
-        case PFMSCAN_TSV_F32: case PFMSCAN_TSV_F64: fixed += 26; break;
-        default: break;
+        case PFMSCAN_TSV_CONST: case PFMSCAN_TSV_FIXED: case PFMSCAN_TSV_WINDOW: bound += col.width; break;
+        case PFMSCAN_TSV_I64: bound += 21; break;
+        case PFMSCAN_TSV_F32: case PFMSCAN_TSV_F64: bound += 26; break;
+        default: {                                   // INDEXED / SPAN: the longest value some row uses
+            const int64_t *index = static_cast<const int64_t *>(col.data);
+            const int64_t *aux = static_cast<const int64_t *>(col.aux);
+            std::vector<int64_t> mx((size_t)threads, 0);
+            parallel_ranges(n_rows, threads, [&](int t, int64_t a, int64_t b) {
+                int64_t m = 0;
+                if (col.kind == PFMSCAN_TSV_INDEXED)
+                    for (int64_t r = a; r < b; ++r) m = std::max(m, aux[index[r] + 1] - aux[index[r]]);
+                else
+                    for (int64_t r = a; r < b; ++r) m = std::max(m, 2 * aux[2 * index[r] + 1] + 2);    // every byte a doubled quote
+                mx[(size_t)t] = m;
+            });
+            for (int64_t m : mx) longest[(size_t)c] = std::max(longest[(size_t)c], m);
+            bound += longest[(size_t)c];
+        }
         }
     }
-    fixed += n_cols + (first_match_id >= 0 ? 21 : 0);
-    const int threads = pick_threads(n_threads, (n_rows + 32767) / 32768);      // a thread is worth starting for ~32k rows
-    struct Part {                                    // a thread's rows: raw storage, never zero-filled
-        char *p = nullptr;
-        size_t cap = 0, used = 0;
-        bool oom = false;
-        ~Part() { std::free(p); }
-    };
-    std::vector<Part> part((size_t)threads);
+    *need = n_rows * bound;
+    *n_pieces = 0;
+    if (*need > capacity) return fail(nullptr, PFMSCAN_E_CAPACITY, "tsv_format: output buffer too small");
+    std::vector<int64_t> used((size_t)threads, 0), from((size_t)threads, 0);
     parallel_ranges(n_rows, threads, [&](int t, int64_t a, int64_t b) {
-        Part &buf = part[(size_t)t];
-        buf.cap = (size_t)std::max<int64_t>(1 << 16, (b - a) * (fixed + 16));
-        buf.p = static_cast<char *>(std::malloc(buf.cap));
-        if (!buf.p) {
-            buf.oom = true;
-            return;
-        }
+        char *const base = out + a * bound;
+        char *p = base;
         for (int64_t r = a; r < b; ++r) {
-            size_t need = (size_t)fixed;
-            for (int c = 0; c < n_cols; ++c)
-                if (cols[c].kind == PFMSCAN_TSV_INDEXED) {
-                    const int64_t *off = static_cast<const int64_t *>(cols[c].aux);
-                    const int64_t v = static_cast<const int64_t *>(cols[c].data)[r];
-                    need += (size_t)(off[v + 1] - off[v]);
-                } else if (cols[c].kind == PFMSCAN_TSV_SPAN) {
-                    const int64_t v = static_cast<const int64_t *>(cols[c].data)[r];
-                    need += 2 * (size_t)static_cast<const int64_t *>(cols[c].aux)[2 * v + 1] + 2;      // every byte a doubled quote
-                }
-            if (buf.used + need > buf.cap) {
-                const size_t cap = std::max(buf.cap * 2, buf.used + need);
-                char *q = static_cast<char *>(std::realloc(buf.p, cap));
-                if (!q) {
-                    buf.oom = true;
-                    return;
-                }
-                buf.p = q;
-                buf.cap = cap;
-            }
-            char *p = buf.p + buf.used;
             for (int c = 0; c < n_cols; ++c) {
                 const pfmscan_tsv_column &col = cols[c];
                 if (c) *p++ = '\t';
@@ -425,22 +412,15 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                 p = put_int(p, first_match_id + r);
             }
             *p++ = '\n';
-            buf.used = (size_t)(p - buf.p);
         }
+        from[(size_t)t] = a * bound;
+        used[(size_t)t] = p - base;
     });
-    int64_t total = 0;
-    for (auto &b : part) {
-        if (b.oom) return fail(nullptr, PFMSCAN_E_OOM, "tsv_format: out of host memory");
-        total += (int64_t)b.used;
+    for (int t = 0; t < threads; ++t) {
+        pieces[2 * t] = from[(size_t)t];
+        pieces[2 * t + 1] = used[(size_t)t];
     }
-    *n_bytes = total;
-    if (total > capacity) return fail(nullptr, PFMSCAN_E_CAPACITY, "tsv_format: output buffer too small");
-    std::vector<int64_t> at((size_t)threads, 0);
-    for (int t = 1; t < threads; ++t) at[(size_t)t] = at[(size_t)t - 1] + (int64_t)part[(size_t)t - 1].used;
-    parallel_ranges(threads, threads, [&](int, int64_t a, int64_t b) {
-        for (int64_t t = a; t < b; ++t)
-            if (part[(size_t)t].used) std::memcpy(out + at[(size_t)t], part[(size_t)t].p, part[(size_t)t].used);
-    });
+    *n_pieces = threads;
     return PFMSCAN_OK;
 }
 

@@ -180,13 +180,14 @@ class TsvWriter(object):
         if n == 0:
             return
         desc = [_descriptor(data[c], n) for c in self.columns]
-        text = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1, scratch=self._scratch)
+        pieces = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1, scratch=self._scratch)
         raw = getattr(self.out, "buffer", None)
         if raw is not None and getattr(self.out, "encoding", "utf-8").lower().replace("-", "") == "utf8":
             self.out.flush()
-            raw.write(text)                      # a text stream over a byte stream: no decode / re-encode of the rows
+            for piece in pieces:
+                raw.write(piece)                 # a text stream over a byte stream: no decode / re-encode of the rows
         else:
-            self.out.write(bytes(text).decode("utf-8"))
+            self.out.write(b"".join(pieces).decode("utf-8"))
         self.rows += n
 
 

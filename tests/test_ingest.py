@@ -130,11 +130,11 @@ def test_float_fields_are_numpys_shortest_repr(dtype, bits):
                             np.inf, -np.inf, np.nan, 5e-324, 1.7976931348623157e308, 1e22, 1e23, 0.1, 0.3, 2.5e-7], dtype=dtype)
     scores = np.round(rng.normal(0, 10, size=100000).astype(dtype), 3)                        # what LogOdds columns hold
     a = np.concatenate([special, scores, raw])
-    got = bytes(_lib.tsv_format([(_lib.TSV_F32 if dtype == np.float32 else _lib.TSV_F64, a, None, None, 0)], a.size)).decode()
+    got = b"".join(_lib.tsv_format([(_lib.TSV_F32 if dtype == np.float32 else _lib.TSV_F64, a, None, None, 0)], a.size)).decode()
     assert got == _float_strings(a)
     if dtype == np.float64:                                                                   # = repr(float), what to_csv writes
         fin = a[np.isfinite(a)][:5000]
-        assert bytes(_lib.tsv_format([(_lib.TSV_F64, fin, None, None, 0)], fin.size)).decode() == "".join(repr(float(x)) + "\n" for x in fin)
+        assert b"".join(_lib.tsv_format([(_lib.TSV_F64, fin, None, None, 0)], fin.size)).decode() == "".join(repr(float(x)) + "\n" for x in fin)
 
 
 def test_writer_bytes_equal_to_csv(tmp_path):
@@ -180,12 +180,12 @@ def test_tsv_format_capacity_and_bad_descriptors():
     L = _lib.load()
     a = np.arange(1000, dtype=np.int64)
     text = _lib.tsv_format([(_lib.TSV_I64, a, None, None, 0)], a.size, 1, estimate=16)        # grows after E_CAPACITY
-    assert bytes(text).decode() == "".join("%d\t%d\n" % (i, i + 1) for i in range(1000))
+    assert b"".join(text).decode() == "".join("%d\t%d\n" % (i, i + 1) for i in range(1000))
     with pytest.raises(ValueError):
         _lib.tsv_format([(9, a, None, None, 0)], a.size)
     with pytest.raises(ValueError):
         _lib.tsv_format([(_lib.TSV_INDEXED, a, None, None, 0)], a.size)
-    assert L.pfmscan_tsv_format(None, 1, 1, -1, None, 0, None, 0) == _lib.E_BADARG
+    assert L.pfmscan_tsv_format(None, 1, 1, -1, None, 0, None, None, None, 0) == _lib.E_BADARG
 
 
 def test_background_counts_natively_equal_the_record_loop(tmp_path):
