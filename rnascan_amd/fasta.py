@@ -205,7 +205,7 @@ class LazyFasta(object):
             lengths.append(idx[4])
         self._file_of = np.concatenate(file_of) if file_of else np.zeros(0, dtype=np.int64)
         self._local_of = np.concatenate(local_of) if local_of else np.zeros(0, dtype=np.int64)
-        self.lengths = (np.concatenate(lengths) if lengths else np.zeros(0, dtype=np.int64)).tolist()
+        self.lengths = np.concatenate(lengths) if lengths else np.zeros(0, dtype=np.int64)
         self.ids = _Headers(self, True)
         self.headers = _Headers(self, False)
 
@@ -267,7 +267,7 @@ class LazyFasta(object):
             offsets.append(o + base)
             base += c.size
             i = j
-        lengths = np.asarray(self.lengths[lo:hi], dtype=np.int64)
+        lengths = np.array(self.lengths[lo:hi], dtype=np.int64)
         if len(codes) == 1:
             return codes[0], offsets[0], lengths
         return np.concatenate(codes), np.concatenate(offsets), lengths
@@ -309,16 +309,12 @@ def _count_rna_natively(fasta_files, positions=1 << 26):
     files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
     if any(os.path.splitext(f)[1] in (".gz", ".bz2") for f in files):
         return None
+    from . import shard
     lazy = LazyFasta(files)
     counts = np.zeros(8, dtype=np.int64)
-    lo = 0
-    while lo < len(lazy):
-        hi, acc = lo, 0
-        while hi < len(lazy) and (hi == lo or acc + lazy.lengths[hi] < positions):
-            acc += lazy.lengths[hi] + 1
-            hi += 1
-        counts += np.bincount(lazy[lo:hi].pack_rna()[0], minlength=8)
-        lo = hi
+    for lo, hi in shard.batches(lazy.lengths, 0, len(lazy), positions):
+        if hi > lo:
+            counts += np.bincount(lazy[lo:hi].pack_rna()[0], minlength=8)
     return counts[:4]
 
 

@@ -59,15 +59,18 @@ def gather_frames(df, rank, world, dist=None):
 def batches(lengths, lo, hi, max_positions):
     """Cut records [lo, hi) into contiguous batches of at most ``max_positions`` stream
     positions sum(L_r + 1) each (a record longer than that is a batch of its own)."""
-    out, start, acc = [], lo, 0
-    for r in range(lo, hi):
-        cost = int(lengths[r]) + 1
-        if r > start and acc + cost > max_positions:
-            out.append((start, r))
-            start, acc = r, 0
-        acc += cost
-    if hi > start or not out:
-        out.append((start, hi))
+    cost = np.cumsum(np.asarray(lengths[lo:hi], dtype=np.int64) + 1)       # cost[i] = positions of records lo .. lo + i
+    out, start, done = [], 0, 0                                            # start: first record of the open batch (relative)
+    n = hi - lo
+    while start < n:
+        # the last record r with cost[r] - done <= max_positions; at least one record per batch
+        end = int(np.searchsorted(cost, done + max_positions, side="right"))
+        end = max(end, start + 1)
+        out.append((lo + start, lo + end))
+        done = int(cost[end - 1])
+        start = end
+    if not out:
+        out.append((lo, hi))
     return out
 
 
