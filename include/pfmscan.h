@@ -283,6 +283,10 @@ int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t
   *   decodes the headers itself). */
 int pfmscan_fasta_ids(const uint8_t *buf, const int64_t *hdr_off, const int64_t *hdr_len,
                       int64_t n_records, int64_t *id_off, int64_t *id_len, int *all_ascii);
+ /* pfmscan_gather_spans: the bytes of n_spans (offset, length) spans of buf, each followed by `separator`, back to back
+  *   in out (all ids or headers of a file as ONE buffer the caller splits); *n_bytes = the size needed / written. */
+int pfmscan_gather_spans(const uint8_t *buf, const int64_t *spans, int64_t n_spans, int separator,
+                         uint8_t *out, int64_t capacity, int64_t *n_bytes);
 int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64_t *seq_end,
                          const int64_t *n_letters, int64_t lo, int64_t hi, const uint8_t *lut256,
                          int separator, uint8_t *codes, int64_t *offsets, int n_threads);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
-    "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_fasta_encode", "pfmscan_tsv_format",
+    "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -123,6 +123,7 @@ def load():
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
+    L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i32), i32]
     for name in SYMBOLS:          # every other entry point returns a status
@@ -185,6 +186,20 @@ def fasta_ids(buf, hdr_off, hdr_len):
     if rc != OK:
         _raise(L, None, rc)
     return np.stack([off, ln], axis=1), bool(ascii_.value)
+
+
+def gather_spans(buf, spans, separator=10):
+    """bytes of the (offset, length) spans of buf, each followed by the separator byte, as one bytes object"""
+    L = load()
+    spans = np.ascontiguousarray(spans, dtype=np.int64)
+    n = int(spans.shape[0])
+    cap = int(spans[:, 1].sum()) + n if n else 0
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    got = ctypes.c_int64(0)
+    rc = L.pfmscan_gather_spans(_ptr(np.asarray(buf)), _ptr(spans), n, int(separator), _ptr(out), cap, ctypes.byref(got))
+    if rc != OK:
+        _raise(L, None, rc)
+    return out[:got.value].tobytes()
 
 
 def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, threads=0):

@@ -284,6 +284,24 @@ int pfmscan_fasta_ids(const uint8_t *buf, const int64_t *hdr_off, const int64_t 
     return PFMSCAN_OK;
 }
 
+int pfmscan_gather_spans(const uint8_t *buf, const int64_t *spans, int64_t n_spans, int separator, uint8_t *out, int64_t capacity,
+                         int64_t *n_bytes)
+{
+    if (n_spans < 0 || (n_spans > 0 && (!buf || !spans)) || !n_bytes || capacity < 0 || (!out && capacity > 0))
+        return fail(nullptr, PFMSCAN_E_BADARG, "gather_spans: bad argument");
+    int64_t total = 0;
+    for (int64_t i = 0; i < n_spans; ++i) total += spans[2 * i + 1] + 1;
+    *n_bytes = total;
+    if (total > capacity) return fail(nullptr, PFMSCAN_E_CAPACITY, "gather_spans: output buffer too small");
+    uint8_t *p = out;
+    for (int64_t i = 0; i < n_spans; ++i) {
+        std::memcpy(p, buf + spans[2 * i], (size_t)spans[2 * i + 1]);
+        p += spans[2 * i + 1];
+        *p++ = (uint8_t)separator;
+    }
+    return PFMSCAN_OK;
+}
+
 int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64_t *seq_end, const int64_t *n_letters,
                          int64_t lo, int64_t hi, const uint8_t *lut256, int separator, uint8_t *codes, int64_t *offsets,
                          int n_threads)

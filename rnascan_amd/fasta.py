@@ -84,16 +84,24 @@ class _Headers(object):
             got = self.cache[i] = (words[0] if words else "", header)
         return got[0] if self.want_id else got[1]
 
+    def tolist(self, lo=0, hi=None):
+        """items [lo, hi) as a list; ASCII headers of a plain file come over in one native gather + one split"""
+        hi = len(self) if hi is None else hi
+        bulk = self.owner._bulk_strings(self.want_id)
+        if bulk is not None:
+            return bulk[lo:hi]
+        return [self._one(i) for i in range(lo, hi)]
+
     def __getitem__(self, key):
         if isinstance(key, slice):
-            return [self._one(i) for i in range(*key.indices(len(self)))]
+            lo, hi, step = key.indices(len(self))
+            return self.tolist(lo, hi)[::step] if step != 1 else self.tolist(lo, hi)
         if key < 0:
             key += len(self)
         return self._one(key)
 
     def __iter__(self):
-        for i in range(len(self)):
-            yield self._one(i)
+        return iter(self.tolist())
 
 
 class _View(object):
@@ -113,8 +121,9 @@ class _View(object):
         return self.seq[self.lo + i]
 
     def __iter__(self):
-        for i in range(self.lo, self.hi):
-            yield self.seq[i]
+        if hasattr(self.seq, "tolist"):
+            return iter(self.seq.tolist(self.lo, self.hi))
+        return iter([self.seq[i] for i in range(self.lo, self.hi)])
 
 
 class FastaSlice(object):
@@ -172,6 +181,7 @@ class LazyFasta(object):
         self.files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
         self._header_cache = {}
         self._spans = {}                       # per file: (id spans, header spans) or None (non-ASCII headers)
+        self._bulk = {}                        # "ids" / "headers" -> list of every record's string, or None
         self._maps = []                        # per file: the mmap object (bytes slices for the headers)
         self._bufs = []                        # per file: uint8 view of the mapped bytes, or None (compressed)
         self._index = []                       # per file: (hdr_off, hdr_len, seq_off, seq_end, n_letters)
@@ -232,6 +242,34 @@ class LazyFasta(object):
             out.append(rec)
         return out
 
+    def _bulk_strings(self, want_id):
+        """every id (or header) as one list, when every file is plain and its headers ASCII; else None"""
+        key = "ids" if want_id else "headers"
+        if key not in self._bulk:
+            out = []
+            for fi in range(len(self.files)):
+                n = 0 if self._index[fi] is None else int(self._index[fi][0].size)
+                tables = self._span_tables_of(fi)
+                if tables is None:
+                    out = None
+                    break
+                if n:
+                    from . import _lib
+                    blob = _lib.gather_spans(self._bufs[fi], tables[0 if want_id else 1])
+                    out.extend(blob.decode("ascii").split("\n")[:n])
+            self._bulk[key] = out
+        return self._bulk[key]
+
+    def _span_tables_of(self, fi):
+        from . import _lib
+        if self._index[fi] is None:
+            return None
+        if fi not in self._spans:
+            idx = self._index[fi]
+            ids, ascii_ = _lib.fasta_ids(self._bufs[fi], idx[0], idx[1])
+            self._spans[fi] = (ids, np.stack([idx[0], idx[1]], axis=1)) if ascii_ else None
+        return self._spans[fi]
+
     def _span_tables(self, lo, hi):
         from . import _lib
         if hi <= lo or (self._parsed and any(i in self._parsed for i in range(lo, hi))):
@@ -239,14 +277,11 @@ class LazyFasta(object):
         fi = int(self._file_of[lo])
         if int(self._file_of[hi - 1]) != fi:
             return None
-        if fi not in self._spans:
-            idx = self._index[fi]
-            ids, ascii_ = _lib.fasta_ids(self._bufs[fi], idx[0], idx[1])
-            self._spans[fi] = (ids, np.stack([idx[0], idx[1]], axis=1)) if ascii_ else None
-        if self._spans[fi] is None:
+        tables = self._span_tables_of(fi)
+        if tables is None:
             return None
         a, b = int(self._local_of[lo]), int(self._local_of[hi - 1]) + 1
-        return self._bufs[fi], self._spans[fi][0][a:b], self._spans[fi][1][a:b]
+        return self._bufs[fi], tables[0][a:b], tables[1][a:b]
 
     def _pack(self, lo, hi, lut):
         from . import _lib

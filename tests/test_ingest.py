@@ -225,3 +225,16 @@ def test_ids_and_headers_as_spans_of_the_mapped_file(tmp_path):
     assert fasta.LazyFasta(path2)[0:3].span_tables() is None
     two = fasta.LazyFasta([path, path])
     assert two[3:7].span_tables() is None and two[5:8].span_tables() is not None        # a slice across two files has no one buffer
+
+
+def test_bulk_ids_equal_the_lazy_ones(tmp_path):
+    data = b">r1 first\nAC\n>  r2\tx \nGG\n>\nA\n>r4\r\nAC\n"
+    path = _write(tmp_path, "b.fa", data)
+    recs = list(fasta.parse_sequences(path))
+    lazy = fasta.LazyFasta(path)
+    assert lazy.ids.tolist() == [r.id for r in recs] and lazy.headers.tolist() == [r.description for r in recs]
+    assert lazy.ids[1:3] == [r.id for r in recs[1:3]] and list(lazy[1:4].ids) == [r.id for r in recs[1:4]]
+    assert [lazy.ids[i] for i in range(4)] == [r.id for r in recs]
+    nasty = fasta.LazyFasta(_write(tmp_path, "n.fa", NASTY))            # a non-ASCII header: decoded one by one as before
+    assert nasty.ids.tolist() == [r.id for r in fasta.parse_sequences(os.path.join(str(tmp_path), "n.fa"))]
+    assert _lib.gather_spans(np.frombuffer(b"abcdef", dtype=np.uint8), np.array([[1, 2], [4, 0], [3, 3]])) == b"bc\n\ndef\n"

@@ -7,6 +7,7 @@ import numpy as np
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 RBIG = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # a second, sequence-only FASTA of this many records
+BIGSTORE = len(sys.argv) > 4 and sys.argv[4] == "store"    # ... with a packed float32 profile store beside it (C3's command line)
 from rnascan_amd import cli, store
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
 d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
@@ -38,6 +39,20 @@ if RBIG:
             n = min(2000, RBIG - lo)
             body = letters[rng.integers(0, 4, size=(n, L))]
             f.write(b"".join(b">t%d transcript %d\n" % (lo + i, lo + i) + body[i].tobytes() + b"\n" for i in range(n)))
+bigsd = os.path.join(d, "bigpacked")
+if RBIG and BIGSTORE:
+    os.makedirs(bigsd)
+    with open(os.path.join(bigsd, "profile.f32"), "wb") as f:
+        for lo in range(0, RBIG, 2000):
+            n = min(2000, RBIG - lo)
+            p = rng.random((n, L + 1, 7), dtype=np.float32)
+            p[p < 0.5] = 0.0                                   # about half exact zeros, like the reference's example profile
+            p /= np.maximum(p.sum(axis=2, keepdims=True), 1e-6)
+            p[:, L] = 0.0
+            f.write(p.tobytes())
+    json.dump({"format": 1, "dtype": "float32", "letters": list("BEHLMRT"), "ids": ["t%d" % i for i in range(RBIG)],
+               "lengths": [L] * RBIG, "n_pos": RBIG * (L + 1), "file": "profile.f32", "separator_rows": "one zero row after each record"},
+              open(os.path.join(bigsd, "index.json"), "w"))
 print("inputs written in %.1f s (%s)" % (time.time() - t0, d), file=sys.stderr)
 runs = [
     ("seq only  -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", fa]),
@@ -52,6 +67,12 @@ runs = [
 if RBIG:
     runs += [("big: seq only -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", big]),
              ("big: seq only -m 2", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", "-m", "2", big])]
+if RBIG and BIGSTORE:
+    for thr in ("0", " -4"):
+        runs.append(("big: seq + struct (store) -m%s" % thr,
+                     ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-q",
+                      os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", thr,
+                      "--profile-dtype", "float32", big, bigsd]))
 for name, argv in runs:
     nrec = RBIG if name.startswith("big") else R
     path = os.path.join(d, "out.tsv")
