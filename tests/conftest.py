@@ -76,3 +76,24 @@ def assert_struct_close(got, want, tol=1e-6):
         assert err.max() <= tol, "max abs err %.3e" % err.max()
     if big.any():
         assert np.allclose(got[big], want[big], rtol=1e-12, atol=0), "huge values differ"
+
+
+def nasty_fasta(path, n=40, seed=3):
+    """records with CRLF, wrapped and blank lines, lower case, T for U, foreign letters, blanks and tabs in the lines,
+    headers that need csv quoting -- some of them holding the SLBP site so that there are hits to format"""
+    rng = np.random.default_rng(seed)
+    site = "AAAGGCTCTTTTCAGAGC"
+    with open(path, "wb") as f:
+        f.write(b"; a comment line before the first record\n")
+        for i in range(n):
+            body = "".join("ACGT"[c] for c in rng.integers(0, 4, size=int(rng.integers(0, 200))))
+            if i % 3 == 0:
+                body = body[:50] + site + body[50:] + (site.lower() if i % 2 else "")
+            if i % 5 == 0:
+                body = body[:20] + "N" + body[20:]
+            eol = "\r\n" if i % 4 == 0 else "\n"
+            header = ">rec%d description %d" % (i, i) + ('\twith a "tab"' if i % 7 == 0 else "") + ("  " if i % 6 == 0 else "")
+            lines = [body[k:k + 60] for k in range(0, len(body), 60)] or [""]
+            if i % 8 == 0:
+                lines[0] = " " + lines[0][:10] + " " + lines[0][10:] + "\t"
+            f.write((header + eol + eol.join(lines) + eol + (eol if i % 9 == 0 else "")).encode("ascii"))

@@ -7,7 +7,7 @@ import shutil
 import numpy as np
 import pytest
 
-from conftest import DATA_DIR
+from conftest import DATA_DIR, nasty_fasta
 
 pytestmark = pytest.mark.gpu
 
@@ -324,3 +324,17 @@ def test_host_pipeline_equals_staged_hits(ctx, oracle, kind):
         ctx.hits_pipeline_host(motif, s.codes if T is not None else None, s.profile if P is not None else None, thr_s, thr_t, 4096, capacity=5)
     assert ei.value.required >= len(want[0])
     motif.close()
+
+
+@pytest.mark.parametrize("minscore", ["8", "-3"])
+def test_cli_on_a_nasty_fasta_equals_the_oracle_engine_run(engine, tmp_path, minscore):
+    """native ingest + the device scan + native rows against the TEST-ONLY oracle engine behind the same CLI: CRLF,
+    wrapped and blank lines, lower case, foreign letters, blanks in the lines, headers that need quoting"""
+    from engines import OracleEngine
+    from rnascan_amd import cli
+    path = str(tmp_path / "n.fa")
+    nasty_fasta(path, n=300, seed=11)
+    got, want = io.StringIO(), io.StringIO()
+    cli.main(["-p", SEQ_PFM, "-u", "-m", minscore, path], engine=engine, out=got)
+    cli.main(["-p", SEQ_PFM, "-u", "-m", minscore, path], engine=OracleEngine(), out=want)
+    assert got.getvalue() == want.getvalue() and got.getvalue().count("\n") > 100

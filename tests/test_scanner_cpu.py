@@ -10,7 +10,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import DATA_DIR
+from conftest import DATA_DIR, nasty_fasta
 from engines import OracleEngine
 from rnascan_amd import cli, fasta, pack, pssm, scanner
 
@@ -313,3 +313,31 @@ def test_combined_scan_over_every_library_pair(tmp_path):
     other = {"X" + k: v for k, v in list(pt.items())[:5]}
     assert scanner.pair_motifs(ps, other) is None
     assert scanner.scan_combined(eng, recs, named, ps, other, -9.0) is None
+
+
+@pytest.mark.parametrize("minscore", ["8", "-3"])
+def test_native_ingest_path_and_record_path_write_the_same_bytes(tmp_path, monkeypatch, minscore):
+    """a plain FASTA goes through pfmscan_fasta_encode / span columns, a gzipped one through Records and Python strings"""
+    import gzip
+    plain = str(tmp_path / "n.fa")
+    nasty_fasta(plain)
+    packed = plain + ".gz"
+    with open(plain, "rb") as src, gzip.open(packed, "wb") as dst:
+        dst.write(src.read())
+    outs = []
+    for path, batch in ((plain, None), (packed, None), (plain, "300")):
+        if batch:
+            monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", batch)        # several batches: Match_ID and buffers carry over
+        out = io.StringIO()
+        cli.main(["-p", SEQ_PFM, "-u", "-m", minscore, path], engine=OracleEngine(), out=out)
+        outs.append(out.getvalue())
+    assert outs[0] == outs[1] == outs[2]
+    rows = outs[0].splitlines()
+    assert len(rows) > (10 if minscore == "8" else 100)
+    df = pd.read_csv(io.StringIO(outs[0]), sep="\t")
+    assert df["Match_ID"].tolist() == list(range(1, len(df) + 1))
+    recs = {r.id: r for r in fasta.parse_sequences(plain)}
+    for r in df.itertuples():                                            # every row is what its record says
+        rec = recs[r.Sequence_ID]
+        assert r.Description == rec.description
+        assert r.Sequence == fasta.preprocess_seq(rec.seq, True)[r.Start - 1:r.End]
