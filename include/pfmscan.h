@@ -260,6 +260,18 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib,
 int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq,
                                uint16_t *credits, double *slack);
 
+/* How the `_host` / `pfmscan_stage` / pipeline entry points move host memory to the device.
+ *   PFMSCAN_UPLOAD_RUNTIME (default): hipMemcpyAsync from the caller's pages; the runtime pins them in place, which
+ *     reaches the PCIe rate for ordinary (anonymous) memory.
+ *   PFMSCAN_UPLOAD_STAGED: transfers of 256 MB and more are cut into 64-MiB pieces that a pool of host threads copies
+ *     into pinned buffers while the DMA engine moves the previous piece.  For a source that is a FILE MAPPING (a packed
+ *     profile store, rnascan/pfmutil.py:61-87 converted once) the page faults are then taken in parallel instead of
+ *     inside the runtime's copy: 32 -> 56 GB/s on a page-cache-warm 4 GB store.
+ * The mode stays set until changed. */
+#define PFMSCAN_UPLOAD_RUNTIME 0
+#define PFMSCAN_UPLOAD_STAGED  1
+int pfmscan_set_upload_mode(pfmscan_ctx *ctx, int mode);
+
 /* ---- host ingest and output (no device needed; no context: errors via pfmscan_last_error(NULL)) ---------------
  * The two pieces of host work that dwarf the kernel at scale, in native code.
  *

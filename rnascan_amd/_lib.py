@@ -33,7 +33,7 @@ SYMBOLS = [
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
-    "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format",
+    "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -121,6 +121,7 @@ def load():
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
+    L.pfmscan_set_upload_mode.argtypes = [vp, i32]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
@@ -143,6 +144,16 @@ def _ptr(a):
     if isinstance(a, np.ndarray):
         return a.ctypes.data_as(ctypes.c_void_p)
     return ctypes.c_void_p(int(a))          # raw device address (e.g. torch.Tensor.data_ptr())
+
+
+def is_file_mapping(a):
+    """True for an array whose memory is a mapped file (numpy memmap or a view of one / of an mmap object)"""
+    import mmap
+    while a is not None:
+        if isinstance(a, (np.memmap, mmap.mmap)):
+            return True
+        a = getattr(a, "base", None)
+    return False
 
 
 def _raise(L, ctx, rc, n_hits=None):
@@ -342,6 +353,7 @@ class Context(object):
         out_struct = np.empty(n, dtype=np.float64) if (want_struct and motif.has_struct) else None
         self.scratch_gen += 1
         self._staged_n = -1
+        self._upload_mode_for(codes, profile)
         self._check(self._L.pfmscan_scan_host(self._h, motif._h, _ptr(codes), _ptr(profile), dt, n,
                                               _ptr(out_seq), _ptr(out_struct)))
         self._staged_n = n                  # scan_host = stage + scan_staged: the stream stays staged
@@ -362,6 +374,7 @@ class Context(object):
         cap = int(capacity) if capacity is not None else max(1024, n // 64)
         self.scratch_gen += 1
         self._staged_n = -1
+        self._upload_mode_for(codes, profile)
         while True:
             pos = np.empty(cap, dtype=np.int64)
             sq = np.empty(cap, dtype=np.float32)
@@ -386,6 +399,7 @@ class Context(object):
         cap = int(capacity) if capacity is not None else max(1024, n // 64)
         self.scratch_gen += 1
         self._staged_n = -1
+        self._upload_mode_for(codes, profile)
         while True:
             pos = np.empty(cap, dtype=np.int64)
             sq = np.empty(cap, dtype=np.float32)
@@ -400,6 +414,14 @@ class Context(object):
             self._check(rc, k.value)
             k = int(k.value)
             return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
+
+    def _upload_mode_for(self, *arrays):
+        """staged uploads (parallel copy into pinned buffers) for sources that are file mappings -- a packed profile
+        store -- and the runtime's in-place pinning for ordinary memory (include/pfmscan.h, pfmscan_set_upload_mode)"""
+        mode = 1 if any(is_file_mapping(a) for a in arrays) else 0
+        if mode != getattr(self, "_upload_mode", 0):
+            self._check(self._L.pfmscan_set_upload_mode(self._h, mode))
+            self._upload_mode = mode
 
     # -- staged stream: upload once, run many motifs ------------------------------------
     def stage(self, codes=None, profile=None):
@@ -425,6 +447,7 @@ class Context(object):
         if n is None:
             raise ValueError("nothing to stage")
         self.scratch_gen += 1
+        self._upload_mode_for(codes, profile)
         self._check(self._L.pfmscan_stage(self._h, _ptr(codes), _ptr(profile), dt, n))
         self._staged_n = n
         return self.scratch_gen

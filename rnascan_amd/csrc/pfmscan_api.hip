@@ -121,6 +121,7 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
                       &ctx->lib_motif, &ctx->lib_seq, &ctx->lib_struct, &ctx->lib_count, &ctx->pipe_codes[0], &ctx->pipe_codes[1],
                       &ctx->pipe_profile[0], &ctx->pipe_profile[1]})
         release(*b);
+    upload_release(ctx);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
         if (ctx->pipe_scanned[i]) (void)hipEventDestroy(ctx->pipe_scanned[i]);
@@ -512,7 +513,7 @@ int pfmscan_stage(pfmscan_ctx *ctx, const uint8_t *codes, const void *profile, i
     if (codes && n_pos > 0) {
         int rc = ensure(ctx, ctx->codes, (size_t)n_pos);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->codes.p, codes, (size_t)n_pos, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload(ctx, ctx->codes.p, codes, (size_t)n_pos, ctx->stream))) return rc;
     }
     if (profile && n_pos > 0) {
         if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
@@ -520,7 +521,7 @@ int pfmscan_stage(pfmscan_ctx *ctx, const uint8_t *codes, const void *profile, i
         size_t bytes = (size_t)n_pos * 7 * (profile_dtype == PFMSCAN_PROFILE_F32 ? 4 : 8);
         int rc = ensure(ctx, ctx->profile, bytes);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->profile.p, profile, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload(ctx, ctx->profile.p, profile, bytes, ctx->stream))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the caller may reuse its buffers
     ctx->staged_n = n_pos;
@@ -584,7 +585,7 @@ int pfmscan_scan_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, con
     ctx->staged_n = -1;                                   // the scratch is about to be overwritten
     int rc = ensure(ctx, ctx->codes, (size_t)n_pos);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->codes.p, codes, (size_t)n_pos, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload(ctx, ctx->codes.p, codes, (size_t)n_pos, ctx->stream))) return rc;
     if ((rc = ensure(ctx, ctx->out_struct, (size_t)n_pos * 8))) return rc;
     rc = pfmscan_scan_letters_f64_dev(ctx, mo, (const uint8_t *)ctx->codes.p, n_pos, (double *)ctx->out_struct.p, ctx->stream);
     if (rc) return rc;

@@ -17,6 +17,10 @@ struct pfmscan_motif {
     int struct_finite = 0;
 };
 
+namespace pfmscan {
+struct Uploader;   // pfmscan_upload.hip: pinned staging buffers + the host threads that fill them
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -38,6 +42,8 @@ struct pfmscan_ctx {
     DevBuf lib_pos, lib_motif, lib_seq, lib_struct, lib_count;   // library scans: sharded hits of the _dev form
     DevBuf pipe_codes[2], pipe_profile[2];      // chunked host pipeline: double-buffered chunk of the stream
     hipEvent_t pipe_copied[2] = {nullptr, nullptr}, pipe_scanned[2] = {nullptr, nullptr};
+    pfmscan::Uploader *up = nullptr;
+    int upload_mode = PFMSCAN_UPLOAD_RUNTIME;
     // staged stream (pfmscan_stage)
     int64_t staged_n = -1;
     int staged_dtype = PFMSCAN_PROFILE_NONE;
@@ -58,6 +64,9 @@ int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_c
 int do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream);
 int finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64_t n_pos, int64_t capacity, int64_t shard_cap,
                        int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits);
+// pfmscan_upload.hip: asynchronous host -> device copy on `st`; the source may be reused when it returns
+int upload(pfmscan_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t st);
+void upload_release(pfmscan_ctx *ctx);
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 }  // namespace pfmscan

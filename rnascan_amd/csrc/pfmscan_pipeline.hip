@@ -71,10 +71,11 @@ int pfmscan_hits_pipeline_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const 
         const int64_t len = std::min<int64_t>(n_pos - a0, chunk_positions + m - 1);
         if (k >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_scanned[b], 0));    // the buffer's previous chunk is scanned
         if (mo->d_letters)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->pipe_codes[b].p, codes + a0, (size_t)len, hipMemcpyHostToDevice, ctx->copy_stream));
+            if (int urc = pfmscan::upload(ctx, ctx->pipe_codes[b].p, codes + a0, (size_t)len, ctx->copy_stream)) return urc;
         if (mo->d_struct)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->pipe_profile[b].p, reinterpret_cast<const unsigned char *>(profile) + (size_t)a0 * row_bytes,
-                                        (size_t)len * row_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            if (int urc = pfmscan::upload(ctx, ctx->pipe_profile[b].p, reinterpret_cast<const unsigned char *>(profile) + (size_t)a0 * row_bytes,
+                                          (size_t)len * row_bytes, ctx->copy_stream))
+                return urc;
         HIP_TRY(ctx, hipEventRecord(ctx->pipe_copied[b], ctx->copy_stream));
         return PFMSCAN_OK;
     };

@@ -338,3 +338,49 @@ def test_cli_on_a_nasty_fasta_equals_the_oracle_engine_run(engine, tmp_path, min
     cli.main(["-p", SEQ_PFM, "-u", "-m", minscore, path], engine=engine, out=got)
     cli.main(["-p", SEQ_PFM, "-u", "-m", minscore, path], engine=OracleEngine(), out=want)
     assert got.getvalue() == want.getvalue() and got.getvalue().count("\n") > 100
+
+
+def test_staged_upload_of_a_mapped_store_equals_the_runtime_copy(ctx, tmp_path, monkeypatch):
+    """PFMSCAN_UPLOAD_STAGED (64-MiB pieces through pinned buffers filled by a thread pool; what a mapped profile store
+    takes from 256 MB on, forced here for a smaller one) moves the same bytes as the runtime's copy: identical hits
+    from pfmscan_stage, the pipeline and hits_host, odd sizes included"""
+    from rnascan_amd import _lib
+    from test_gpu_parity import rand_struct_pssm, rand_table
+    rng = np.random.default_rng(21)
+    n_pos = 2_600_017                                        # 72.8 MB of float32 rows: one full piece + a ragged one
+    prof = rng.random((n_pos, 7), dtype=np.float32)
+    prof /= prof.sum(axis=1, keepdims=True)
+    prof[::3001] = 0.0
+    codes = rng.integers(0, 4, size=n_pos).astype(np.uint8)
+    codes[::3001] = 7
+    path = str(tmp_path / "p.f32")
+    prof.tofile(path)
+    mapped = np.memmap(path, dtype=np.float32, mode="r", shape=(n_pos, 7))
+    assert _lib.is_file_mapping(mapped[5:100]) and not _lib.is_file_mapping(prof)
+    m = 12
+
+    def same(got, want):                                      # the fused and the two-pass kernels differ in the last bits of a structure score
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+        assert np.abs(got[2] - want[2]).max() <= 1e-9
+
+    motif = ctx.motif(rand_table(rng, m, 4), rand_struct_pssm(rng, m, inf_frac=0.0))
+    monkeypatch.setenv("PFMSCAN_UPLOAD", "0")
+    want = ctx.hits_host(motif, codes, prof, 2.0, -1e30)
+    assert len(want[0]) > 1000
+    monkeypatch.setenv("PFMSCAN_UPLOAD", "1")
+    for src in (mapped, prof):
+        got = ctx.hits_host(motif, codes, src, 2.0, -1e30)
+        same(got, want)
+        got = ctx.hits_pipeline_host(motif, codes, src, 2.0, -1e30, 1 << 21)
+        same(got, want)
+    ctx.stage(codes, mapped)
+    got = ctx.hits_staged(motif, 2.0, -1e30)
+    same(got, want)
+    monkeypatch.delenv("PFMSCAN_UPLOAD")
+    ctx.stage(codes, mapped)                                  # the mode a mapped source selects by itself (below 256 MB: plain copy)
+    assert ctx._upload_mode == 1
+    got = ctx.hits_staged(motif, 2.0, -1e30)
+    same(got, want)
+    ctx.stage(codes, prof)
+    assert ctx._upload_mode == 0
+    motif.close()
