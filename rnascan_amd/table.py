@@ -83,6 +83,19 @@ def column_length(col):
     return len(col)
 
 
+def _rows(col, a, b):
+    """rows [a, b) of a column, same kind"""
+    if isinstance(col, Indexed):
+        return Indexed(col.values, col.index[a:b])
+    if isinstance(col, Spans):
+        return Spans(col.buffer, col.spans, col.index[a:b])
+    if isinstance(col, Windows):
+        return Windows(col.codes, col.pos[a:b], col.m, col.letters)
+    if column_length(col) is None:
+        return col
+    return col[a:b]
+
+
 def to_frame(columns, order=None):
     """compact columns -> pandas DataFrame (the non-streaming consumers: joins, multi-rank gathers, the API)"""
     import pandas as pd
@@ -166,6 +179,8 @@ class TsvWriter(object):
     """write_chunk(columns) appends rows; columns is an ordered mapping name -> array | list | scalar |
     Indexed | Spans | Windows (a DataFrame's columns work as arrays)."""
 
+    MAX_ROWS = 1 << 22                          # rows per native call (~0.5 GB of row buffer at the widest tables)
+
     def __init__(self, out, columns, match_id=True):
         self.out = out
         self.columns = list(columns)
@@ -178,6 +193,11 @@ class TsvWriter(object):
         if n is None:
             n = next((k for k in (column_length(data[c]) for c in self.columns) if k is not None), 0)
         if n == 0:
+            return
+        if n > self.MAX_ROWS:                    # an all-scores table (-m ' -inf'): bound the row buffer, not the table
+            for a in range(0, n, self.MAX_ROWS):
+                b = min(n, a + self.MAX_ROWS)
+                self.write_chunk({c: _rows(data[c], a, b) for c in self.columns}, b - a)
             return
         desc = [_descriptor(data[c], n) for c in self.columns]
         pieces = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1, scratch=self._scratch)

@@ -163,6 +163,11 @@ def test_writer_bytes_equal_to_csv(tmp_path):
     out = io.StringIO()                                  # the same table as a DataFrame, in uneven chunks
     table.write_frame(out, df, chunk=777)
     assert out.getvalue() == expected
+    out = io.StringIO()                                  # more rows than one native call takes: cut inside write_chunk
+    w = table.TsvWriter(out, list(cols))
+    w.MAX_ROWS = 999
+    w.write_chunk(cols)
+    assert out.getvalue() == expected
     path = os.path.join(str(tmp_path), "o.tsv")          # a real text file: rows go to its byte buffer
     with open(path, "w", encoding="utf-8", newline="") as f:
         w = table.TsvWriter(f, list(cols))
@@ -238,3 +243,11 @@ def test_bulk_ids_equal_the_lazy_ones(tmp_path):
     nasty = fasta.LazyFasta(_write(tmp_path, "n.fa", NASTY))            # a non-ASCII header: decoded one by one as before
     assert nasty.ids.tolist() == [r.id for r in fasta.parse_sequences(os.path.join(str(tmp_path), "n.fa"))]
     assert _lib.gather_spans(np.frombuffer(b"abcdef", dtype=np.uint8), np.array([[1, 2], [4, 0], [3, 3]])) == b"bc\n\ndef\n"
+
+
+def test_index_of_very_short_records_takes_the_exact_count_retry():
+    data = b"".join(b">r%d\nAC\n" % i for i in range(5000))           # 8-9 bytes per record: more records than size // 64
+    buf = np.frombuffer(data, dtype=np.uint8)
+    ix = _lib.fasta_index(buf)
+    assert ix[0].size == 5000 and ix[4].tolist() == [2] * 5000
+    assert data[ix[0][4999]:ix[0][4999] + ix[1][4999]] == b"r4999"
