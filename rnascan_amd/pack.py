@@ -77,10 +77,11 @@ class Stream(object):
 
     def window_mask(self, m):
         """bool [n_pos]: True where a window of width m lies inside one record."""
-        mask = np.zeros(self.n_pos, dtype=bool)
-        for r in range(self.n_records):
-            mask[self.record_slice(r, m)] = True
-        return mask
+        n = np.maximum(self.lengths - m + 1, 0)
+        edge = np.zeros(self.n_pos + 1, dtype=np.int8)       # +1 at a record's first window, -1 after its last one
+        np.add.at(edge, self.offsets, 1)
+        np.add.at(edge, self.offsets + n, -1)
+        return np.cumsum(edge[:-1], dtype=np.int8).astype(bool)
 
 
 def pack(code_arrays=None, profiles=None, profile_dtype=np.float32):
