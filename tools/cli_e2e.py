@@ -56,6 +56,8 @@ if RBIG and BIGSTORE:
 print("inputs written in %.1f s (%s)" % (time.time() - t0, d), file=sys.stderr)
 runs = [
     ("seq only  -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", fa]),
+    ("seq only  -m -inf (every window a row)", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u",
+                                                "-m", " -inf", fa]),
     ("struct only (store) -m 6", ["-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", sd]),
     ("seq + struct (store) -m 0", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"),
                                    "-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", "0",
@@ -89,5 +91,5 @@ for name, argv in runs:
             prof.disable()
             pstats.Stats(prof, stream=sys.stdout).sort_stats("tottime").print_stats(12)
     rows = sum(1 for _ in open(path, "rb")) - 1
-    print("%-28s %.2f s   %d rows   %.3g windows/s   %.1f MB of table" % (name, dt, rows, nrec * (L - 17) / dt,
+    print("%-40s %.2f s   %d rows   %.3g windows/s   %.1f MB of table" % (name, dt, rows, nrec * (L - 17) / dt,
                                                                          os.path.getsize(path) / 1e6))
