@@ -427,11 +427,18 @@ def main():
             info = library.info()
             npair = (args.width + 1) // 2
             lds_bytes = float(windows) * n_motifs * npair * 2
+            # what the look-ups really move: one 16-byte entry per (window, pair row, motif group); a group holds 12 motifs
+            # (10-bit credits, widths up to 16) or 8 (16-bit credits), padding motifs of the last group included
+            mpg = 12 if args.width <= 16 else 8
+            groups = sum(-(-min(info["motifs_per_pass"], n_motifs - i * info["motifs_per_pass"]) // mpg) for i in range(info["passes"]))
+            lds_read = float(windows) * groups * npair * 16
             lds_peak = 256 * 256 * 2.4                      # CUs x B/clk/CU x GHz = GB/s (MI355X_MICROARCH.md, LDS)
             cand = windows * n_motifs * rate_seq if thr_note != "given" else None
             result["roofline"] = {
                 "bound": "lds", "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": lds_peak, "unit": "GB/s",
-                "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / lds_peak, "traffic": None, "traffic_source": None,
+                "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / lds_peak, "traffic": lds_read,
+                "traffic_source": "computed, not measured: 16-byte table entries of %d motifs read by phase A (LDS, not HBM, bytes); "
+                                  "the exact pass's gathers come on top" % mpg,
                 "kernel": "k_library (x%d passes of <= %d motifs)" % (info["passes"], info["motifs_per_pass"]),
                 "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
                 "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": lds_bytes,

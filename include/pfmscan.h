@@ -253,11 +253,13 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib,
                               int64_t capacity, int64_t *hit_pos, int32_t *hit_motif,
                               float *hit_seq, double *hit_struct, int64_t *n_hits);
 
-/* Diagnostics (host only, no device needed): the unsigned 16-bit two-letter credit table the library kernel's
- * prefilter uses for ONE motif (letter_table double [m][8], 4-letter alphabet) at threshold thr_seq:
- * credits uint16 [ceil(m/2)][16], entry index c0 | c1 << 2.  A window whose credits sum modulo 65536 has bit 15
- * clear cannot be a hit; *slack = how far below the threshold a kept window's score may lie (score units). */
-int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq,
+/* Diagnostics (host only, no device needed): the unsigned two-letter credit table the prefilters use for ONE motif
+ * (letter_table double [m][8], 4-letter alphabet) at threshold thr_seq: credits uint16 [ceil(m/2)][16], entry index
+ * c0 | c1 << 2, with `bits` = 16 (k_letters_cred; k_library for PFMs wider than 16), 10 (k_library up to width 16:
+ * three credits per dword, twelve motifs per 16-byte table entry) or 0 (what k_library uses at this width).  A window
+ * whose credits sum modulo 2^bits has bit (bits - 1) clear cannot be a hit; *slack = how far below the threshold a kept
+ * window's score may lie (score units). */
+int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq, int bits,
                                uint16_t *credits, double *slack);
 
 /* How the `_host` / `pfmscan_stage` / pipeline entry points move host memory to the device.

@@ -120,7 +120,7 @@ def load():
     L.pfmscan_library_hits_staged.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
-    L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
+    L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, i32, vp, ctypes.POINTER(dbl)]
     L.pfmscan_set_upload_mode.argtypes = [vp, i32]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
@@ -636,10 +636,12 @@ class Library(object):
             pass
 
 
-def credit_table(letter_table, thr_seq):
-    """Host-only diagnostic (no device needed): the unsigned 16-bit two-letter credit table the library kernel's
-    prefilter uses for ONE motif at threshold ``thr_seq`` -> (credits uint16 [ceil(m/2)][16], slack in score units).
-    A window whose credits sum (mod 65536) has bit 15 clear cannot be a hit; tests check that exhaustively."""
+def credit_table(letter_table, thr_seq, bits=16):
+    """Host-only diagnostic (no device needed): the unsigned two-letter credit table the integer prefilters use for
+    ONE motif at threshold ``thr_seq`` -> (credits uint16 [ceil(m/2)][16], slack in score units).  ``bits`` = 16, 10
+    (the library kernel's twelve-motifs-per-entry form for widths up to 16) or 0 (what the library kernel uses at
+    this width).  A window whose credits sum (mod 2**bits) has bit bits - 1 clear cannot be a hit; tests check that
+    exhaustively."""
     L = load()
     T = np.ascontiguousarray(letter_table, dtype=np.float64)
     if T.ndim != 2 or T.shape[1] != NCODE:
@@ -647,7 +649,7 @@ def credit_table(letter_table, thr_seq):
     m = T.shape[0]
     out = np.zeros(((m + 1) // 2, 16), dtype=np.uint16)
     slack = ctypes.c_double(0.0)
-    rc = L.pfmscan_debug_credit_table(_ptr(T), m, float(thr_seq), _ptr(out), ctypes.byref(slack))
+    rc = L.pfmscan_debug_credit_table(_ptr(T), m, float(thr_seq), int(bits), _ptr(out), ctypes.byref(slack))
     if rc != OK:
         raise ValueError("pfmscan_debug_credit_table: bad argument")
     return out, slack.value

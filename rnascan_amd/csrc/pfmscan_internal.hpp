@@ -63,7 +63,7 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
 // Credits of ONE motif at threshold thr (pfmscan_library_api.hip): pairsum [npair][16] exact two-letter sums ->
 // out [npair][16] unsigned 16-bit credits with the threshold folded into row 0; "bit 15 of the sum clear" => the
 // window cannot be a hit.  Returns the one-sided slack in score units (inf: no prefilter possible).  Host code.
-double build_credits(const double *pairsum, int npair, double thr, uint16_t *out);
+double build_credits(const double *pairsum, int npair, double thr, uint16_t *out, int bits = 16);
 void pair_sums(const double *letter_table, int m, double *out);      // [m][8] -> [ceil(m/2)][16]
 
 // Second phase of the candidate-then-verify combined scan: structure score of the windows
@@ -101,7 +101,11 @@ struct GatherArgs {
 // one workgroup per CU, its waves independent and sharing the LDS tables: 16 waves (128 VGPRs each) for PFMs up to
 // width 32, 8 waves (256 VGPRs) for the widest bucket, whose 32 pair addresses per lane would otherwise spill
 __host__ __device__ constexpr int lib_block(int np_bucket) { return np_bucket > 16 ? 512 : 1024; }
-constexpr int LIB_QCAP = 128;             // (window, motif octet) items a wave can park (>= 64 + 63)
+constexpr int LIB_QCAP = 128;             // (window, motif group) items a wave can park (>= 64 + 63)
+// motifs per 16-byte table entry and bits per credit: PFMs up to width 16 (at most 8 pair rows) pack THREE 10-bit credits
+// per dword (12 motifs per look-up, V = 511 / (npair - 1) >= 73 levels per row), wider ones two 16-bit credits (8 motifs)
+__host__ __device__ constexpr int lib_mpg(int np_bucket) { return np_bucket == 8 ? 12 : 8; }
+__host__ __device__ constexpr int lib_credit_bits(int np_bucket) { return np_bucket == 8 ? 10 : 16; }
 constexpr int LIB_SHARDS = 256;           // sharded hit buffers of a library scan: workgroup b appends to shard b & 255
 
 struct LibArgs {
@@ -126,11 +130,11 @@ struct LibArgs {
     double *hit_struct;
     unsigned long long *hit_count;
 };
-size_t lib_motif_bytes(int m, int npair, bool has_struct);     // LDS bytes per motif of a pass
+size_t lib_group_bytes(int m, int npair, bool has_struct, int np_bucket);   // LDS bytes per motif group of a pass
 size_t lib_queue_bytes(int np_bucket);                          // LDS bytes of the wave queues
-size_t lib_lds_bytes(int m, int npair, int nmp, bool has_struct, int np_bucket);
+size_t lib_lds_bytes(int m, int npair, int ng, bool has_struct, int np_bucket);
 int lib_np_bucket(int m);
-int lib_pick_ng(int np_bucket, int want_octets, int max_octets);   // supported octet count of a pass (0: none fits)
+int lib_pick_ng(int np_bucket, int want_groups, int max_groups);   // supported group count of a pass (0: none fits)
 hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream);
 
 hipError_t sort_temp_bytes(int64_t total, int key_bits, size_t *bytes);

@@ -5,20 +5,21 @@
 // (pfmutil.py:89-133).  A hit of motif k at window p needs seq_k(p) > thr_seq[k] (pssm.search, rnascan.py:263,
 // strict) AND struct_k(p) > thr_struct[k] (rnascan.py:310), the inner join of combine() (rnascan.py:422-423).
 //
-// Per motif-window the letters side costs ceil(m/2) table look-ups, so a library scan is bound by LDS look-up
-// and VALU issue rate, not by HBM (the codes are read once for all motifs of a pass).  Design:
+// Per motif-window the letters side costs ceil(m/2) table look-ups, so a library scan is bound by the LDS look-up
+// rate, not by HBM (the codes are read once for all motifs of a pass).  Design:
 //
 //  phase A (every window x every motif): "can this window be a hit?" from two-letter CREDIT tables: unsigned
-//      16-bit fixed point, EIGHT motifs interleaved per 16-byte entry ([pair row][octet][16 entries][8 motifs] in
-//      LDS) -> one ds_read_b128 per (window, pair row, 8 motifs), two motifs per 32-bit add, two rows per
-//      v_add3_u32.  Integer adds are exact and the host rounds every credit UP (pfmscan_library_api.hip), so the
-//      test can only err towards keeping a window.  The threshold is folded into pair row 0 so that "may be a
-//      hit" is "bit 15 set": an OR over the four accumulator registers tests 8 motifs at once.  A lane owns ONE
-//      window; its pair offsets are computed once per window and serve every octet, and because the octet count
-//      NG is a template parameter every table offset is an immediate of the ds_read.  Windows covering a
-//      foreign letter or separator are dropped here (their exact score is NaN, _pwm.c:61-66).
-//  queue: a flagged (window, motif octet) goes to the wave's private LDS queue (position, octet, the accumulators' flag
-//      bytes as they are): no atomics, waves never synchronise with each other.
+//      fixed point, a GROUP of motifs interleaved per 16-byte entry ([pair row][group][16 entries][4 dwords] in LDS):
+//      TWELVE 10-bit credits for PFMs up to width 16 (three per dword), EIGHT 16-bit ones beyond -> one ds_read_b128
+//      per (window, pair row, group), 3 or 2 motifs per 32-bit add, two rows per v_add3_u32.  Integer adds are exact
+//      and the host quantises every deficit DOWN (pfmscan_library_api.hip), so the test can only err towards keeping
+//      a window.  The threshold is folded into pair row 0 so that "may be a hit" is the top bit of a credit sum: an
+//      OR over the four accumulator registers and one mask test a whole group.  A lane owns ONE window; its pair
+//      offsets are computed once per window and serve every group, and because the group count NG is a template
+//      parameter every table offset is an immediate of the ds_read.  Windows covering a foreign letter or separator
+//      are dropped here (their exact score is NaN, _pwm.c:61-66).
+//  queue: a flagged (window, motif group) goes to the wave's private LDS queue (position, group, the accumulators' flag
+//      bits): no atomics, waves never synchronise with each other.
 //  phase B (dense, once 64 items wait): one item per lane.  The window's letters are read again (L2); the exact score
 //      is the sequential fp64 sum of _pwm.c:34-68 from an LDS copy of the fp64 letter tables, cast to float32 and compared with the threshold --
 //      only that decides.  A window that passes gets the exact structure score of rnascan.py:302-307
@@ -26,9 +27,9 @@
 //      L1/L2), the motif's PSSM from LDS.  Hits are compacted inside the wave; one returning atomic per batch on
 //      one of 256 sharded counters.
 //
-// LDS per motif at width m: (ceil(m/2)+1)*32 B (credits) + m*32 B (fp64 letters) + m*64 B (fp64 structure PSSM)
-// + 16 B thresholds; a library larger than the 160 KB allow is scanned in several passes (256 pairs of width 12:
-// passes of 96 / 96 / 64 motifs), each re-reading only the 1-byte codes.
+// LDS per motif group at width m: (ceil(m/2)+1)*256 B (credits + the zero row) and, per motif, m*32 B (fp64 letters)
+// + m*64 B (fp64 structure PSSM) + 16 B thresholds; a library larger than the 160 KB allow is scanned in several
+// passes (256 pairs of width 12: passes of 96 / 96 / 64 motifs = 8 / 8 / 6 groups), each re-reading only the 1-byte codes.
 #include <float.h>
 #include <math.h>
 
@@ -109,9 +110,9 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
     return score;
 }
 
-// Credits of one motif octet for the lane's window: K pair rows (compile-time), every look-up in flight before the
+// Credits of one motif group for the lane's window: K pair rows (compile-time), every look-up in flight before the
 // first add (8 rows at a time for wide PFMs), two rows per v_add3_u32.  rowp[t] points at the lane's entry of pair
-// row t in octet 0; `off` (bytes, = octet * 256) is an immediate when it is a constant.
+// row t in group 0; `off` (bytes, = group * 256) is an immediate when it is a constant.
 template <int K, int NP>
 __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const int off)
 {
@@ -140,27 +141,35 @@ __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const i
     return acc;
 }
 
-// flagged lanes of one octet -> the wave's queue.  mk = ballot of the flags (non-zero), qn = queue length.  An item is
-// three dwords: the window's position, and the flag BYTES of the 8 accumulators as they are (bit 7 of each byte = bit 15
-// of a credit sum): p0 = {x.lo, x.hi, y.lo, y.hi} = motifs 8g .. 8g+3, p1 = {z.lo, z.hi, w.lo, w.hi} = motifs 8g+4 .. 8g+7,
-// with the octet g in bits 0-5 of p1.  Decoding is phase B's business: here every instruction counts (phase A is bound by
-// VALU issue, and three octets out of four have a flagged lane somewhere in the wave).
+// flagged lanes of one group -> the wave's queue.  mk = ballot of the flags (non-zero), qn = queue length.  An item is
+// the window's position and the flag bits of the accumulators, decoded in phase B (the push itself is the rare path:
+// ~1.3 items per group and chunk):
+//   8 motifs per entry (16-bit credits): p0 = the four sign BYTES of x, y (motifs 0..3), p1 = those of z, w (motifs 4..7)
+//     with the group g in bits 0-5 of p1;
+//   12 motifs per entry (10-bit credits, fields at bits 0 / 10 / 20 of a dword): p0 = bit (10 f + d) for motif 3 d + f,
+//     with the group g in bits 24-29.
+template <int MPG>
 __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const unsigned long long mk, const int qn, const int g,
                                          const uint32_t relpos, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     if (flag) {
-        const uint32_t p0 = __builtin_amdgcn_perm(acc.y, acc.x, 0x07050301u);
-        const uint32_t p1 = __builtin_amdgcn_perm(acc.w, acc.z, 0x07050301u);
         const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
         q_pos[slot] = relpos;
-        q_p0[slot] = p0;
-        q_p1[slot] = (p1 & ~0x3Fu) | (uint32_t)g;          // v_bfi_b32
+        if constexpr (MPG == 12) {
+            constexpr uint32_t M = 0x20080200u;
+            q_p0[slot] = ((acc.x & M) >> 9) | ((acc.y & M) >> 8) | ((acc.z & M) >> 7) | ((acc.w & M) >> 6) | ((uint32_t)g << 24);
+        } else {
+            const uint32_t p0 = __builtin_amdgcn_perm(acc.y, acc.x, 0x07050301u);
+            const uint32_t p1 = __builtin_amdgcn_perm(acc.w, acc.z, 0x07050301u);
+            q_p0[slot] = p0;
+            q_p1[slot] = (p1 & ~0x3Fu) | (uint32_t)g;          // v_bfi_b32
+        }
     }
 }
 
-// Phase A, fast path: all NG octets of the lane's window, fully unrolled (immediate table offsets).  Pushes while
-// the queue has room; returns the first octet that did NOT fit (NG when all did) -- from there the slow path takes
-// over after a drain.  A chunk brings ~1.3 items per octet at realistic thresholds, the queue takes >= 65.
+// Phase A, fast path: all NG groups of the lane's window, fully unrolled (immediate table offsets).  Pushes while
+// the queue has room; returns the first group that did NOT fit (NG when all did) -- from there the slow path takes
+// over after a drain.  A chunk brings one or two items per group at realistic thresholds, the queue takes >= 65.
 template <int K, int NG, int NP>
 __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
                                                uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
@@ -170,7 +179,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
-        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x80008000u) != 0u;
+        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
         if (mk && g_next == NG) {                     // wave-uniform
             const int n = __popcll(mk);
@@ -181,15 +190,15 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
             g_next = fits ? NG : g;
             qs = fits ? qs + n : qs;
             asm volatile("" : "+s"(qs), "+s"(g_next));
-            if (fits) lib_push(acc, flag, mk, at, g, relpos, q_pos, q_p0, q_p1);
+            if (fits) lib_push<lib_mpg(NP)>(acc, flag, mk, at, g, relpos, q_pos, q_p0, q_p1);
         }
     }
     qn = qs;
     return g_next;
 }
 
-// Phase A, slow path: octets g .. NG-1 one by one (runtime table offset), stopping as soon as 64 items wait.
-// Needs qn < 64 on entry (an octet brings at most 64 items, the queue holds LIB_QCAP >= 127).
+// Phase A, slow path: groups g .. NG-1 one by one (runtime table offset), stopping as soon as 64 items wait.
+// Needs qn < 64 on entry (a group brings at most 64 items, the queue holds LIB_QCAP >= 127).
 template <int K, int NG, int NP>
 __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
                                                uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
@@ -198,10 +207,10 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
     g = __builtin_amdgcn_readfirstlane(g);
     while (g < NG && qs < 64) {
         const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
-        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x80008000u) != 0u;
+        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
         if (mk) {
-            lib_push(acc, flag, mk, qs, g, relpos, q_pos, q_p0, q_p1);
+            lib_push<lib_mpg(NP)>(acc, flag, mk, qs, g, relpos, q_pos, q_p0, q_p1);
             qs += __popcll(mk);
         }
         ++g;
@@ -227,13 +236,14 @@ __device__ __forceinline__ int lib_dispatch(const int npair, const int g, const 
     }
 }
 
-// NG = motif octets of the pass, NP = pair rows the code is unrolled for (8 / 16 / 32 for m <= 16 / 32 / 64)
+// NG = motif groups of the pass, NP = pair rows the code is unrolled for (8 / 16 / 32 for m <= 16 / 32 / 64)
 template <int NG, int NP, typename PROF_T, bool HAS_STRUCT>
 __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 {
     constexpr int LIB_BLOCK = lib_block(NP);
     constexpr int LIB_WAVES = LIB_BLOCK / 64;
-    constexpr int NMP = NG * 8;                     // motifs of the pass (padding motifs never flag)
+    constexpr int MPG = lib_mpg(NP);                // motifs per table entry: 12 (10-bit credits) or 8 (16-bit)
+    constexpr int NMP = NG * MPG;                   // motifs of the pass (padding motifs never flag)
     constexpr int NRAW = NP / 2 + 1;                // aligned code dwords a lane loads
     extern __shared__ __align__(16) unsigned char smem[];
     const int m = a.m, npair = a.npair;
@@ -280,11 +290,11 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const bool have = lane < cnt;
         const int idx = first + (have ? lane : 0);
         const uint32_t rel = q_pos[idx];
-        const uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
-        // byte b, bit 0 = motif 8g + b flagged, bit 1 = motif 8g + 4 + b flagged
-        uint32_t bits = have ? (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u)) : 0u;
-        const uint32_t g = p1 & 0x3Fu;
-        const int g8 = (int)g * 8;
+        const uint32_t p0 = q_p0[idx], p1 = MPG == 12 ? 0u : q_p1[idx];
+        // bits: one per flagged motif of the group; slot_of(bit) = its motif within the group
+        //   8 per entry: byte b, bit 0 = motif b, bit 1 = motif 4 + b;   12 per entry: bit 10 f + d = motif 3 d + f
+        uint32_t bits = !have ? 0u : (MPG == 12 ? (p0 & 0x00F03C0Fu) : (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u)));
+        const uint32_t g = MPG == 12 ? (p0 >> 24) : (p1 & 0x3Fu);
         const int64_t p = a.pos_base + (int64_t)rel;
         const bool act = bits != 0;
         const int q = act ? __builtin_ctz(bits) : 0;
@@ -296,8 +306,12 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (bits != 0) {
                 const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
-                q_p0[slot] = (bits & 0x01010101u) << 7;
-                q_p1[slot] = ((bits & 0x02020202u) << 6) | g;
+                if (MPG == 12) {
+                    q_p0[slot] = bits | (g << 24);
+                } else {
+                    q_p0[slot] = (bits & 0x01010101u) << 7;
+                    q_p1[slot] = ((bits & 0x02020202u) << 6) | g;
+                }
             }
             requeued = __popcll(more);
         } else {
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 #pragma unroll
             for (int k = 0; k < NP / 2; ++k) w[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
         }
-        const int mo = g8 + (q >> 3) + 4 * (q & 1);   // pass-local motif
+        const int mo = (int)g * MPG + (MPG == 12 ? 3 * (q % 10) + q / 10 : (q >> 3) + 4 * (q & 1));   // pass-local motif
         // exact sequence score: sequential fp64 sum (_pwm.c:36-64), float32 cast (:65)
         double sc = 0.0;
         const double *L = letters + mo;
@@ -413,36 +427,37 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     }
 }
 
-// LDS bytes of one pass (must match the carve-up in k_library)
-size_t lib_motif_bytes(int m, int npair, bool has_struct)
+// LDS bytes of one motif group of a pass (must match the carve-up in k_library): its slice of every pair row and of the
+// zero row, and the exact tables + thresholds of its motifs
+size_t lib_group_bytes(int m, int npair, bool has_struct, int np_bucket)
 {
-    return (size_t)(npair + 1) * 32 + (size_t)m * 32 + (has_struct ? (size_t)m * 64 : 0) + 16;     // +1: the zero row
+    return (size_t)(npair + 1) * 256 + (size_t)lib_mpg(np_bucket) * ((size_t)m * 32 + (has_struct ? (size_t)m * 64 : 0) + 16);
 }
 
 size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * 3 * 4; }
 
-size_t lib_lds_bytes(int m, int npair, int nmp, bool has_struct, int np_bucket)
+size_t lib_lds_bytes(int m, int npair, int ng, bool has_struct, int np_bucket)
 {
-    return lib_motif_bytes(m, npair, has_struct) * (size_t)nmp + lib_queue_bytes(np_bucket);
+    return lib_group_bytes(m, npair, has_struct, np_bucket) * (size_t)ng + lib_queue_bytes(np_bucket);
 }
 
 int lib_np_bucket(int m) { return m <= 16 ? 8 : (m <= 32 ? 16 : 32); }
 
-// octet counts a pass may have (each is a kernel instantiation), largest first
-static const int LIB_NG_8[] = {16, 12, 8, 4, 2};
+// group counts a pass may have (each is a kernel instantiation), largest first
+static const int LIB_NG_8[] = {16, 11, 8, 6, 4, 2};
 static const int LIB_NG_16[] = {8, 4, 2};
 static const int LIB_NG_32[] = {4, 2};
 
-// the smallest supported octet count >= want_octets that is <= max_octets; when none is large enough, the largest
-// one within max_octets (the caller then needs more passes); 0 when even the smallest does not fit
-int lib_pick_ng(int np_bucket, int want_octets, int max_octets)
+// the smallest supported group count >= want_groups that is <= max_groups; when none is large enough, the largest
+// one within max_groups (the caller then needs more passes); 0 when even the smallest does not fit
+int lib_pick_ng(int np_bucket, int want_groups, int max_groups)
 {
     const int *set = np_bucket == 8 ? LIB_NG_8 : (np_bucket == 16 ? LIB_NG_16 : LIB_NG_32);
-    const int n = np_bucket == 8 ? 5 : (np_bucket == 16 ? 3 : 2);
+    const int n = np_bucket == 8 ? 6 : (np_bucket == 16 ? 3 : 2);
     int best = 0;
     for (int i = 0; i < n; ++i) {
-        if (set[i] > max_octets) continue;
-        if (best == 0 || set[i] >= want_octets) best = set[i];
+        if (set[i] > max_groups) continue;
+        if (best == 0 || set[i] >= want_groups) best = set[i];
     }
     return best;
 }
@@ -473,14 +488,15 @@ hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream)
 {
     if (a.span <= 0 || a.nmp <= 0) return hipSuccess;
     const int np = lib_np_bucket(a.m);
-    const size_t lds = lib_lds_bytes(a.m, a.npair, a.nmp, a.pssm != nullptr, np);
-    if (lds > 160 * 1024 || a.ng * 8 != a.nmp || (a.seg_positions & 1023)) return hipErrorInvalidValue;
+    const size_t lds = lib_lds_bytes(a.m, a.npair, a.ng, a.pssm != nullptr, np);
+    if (lds > 160 * 1024 || a.ng * lib_mpg(np) != a.nmp || (a.seg_positions & 1023)) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)std::min<int64_t>(a.n_seg, n_cu);
 #define LIB_CASE(NGV, NPV) \
     if (np == NPV && a.ng == NGV) return launch_library_ng<NGV, NPV>(a, grid, lds, stream)
     LIB_CASE(16, 8);
-    LIB_CASE(12, 8);
+    LIB_CASE(11, 8);
     LIB_CASE(8, 8);
+    LIB_CASE(6, 8);
     LIB_CASE(4, 8);
     LIB_CASE(2, 8);
     LIB_CASE(8, 16);

@@ -7,10 +7,12 @@
 //     |S64 - S| and the float32 rounding stay below delta = 2^-23 * sum_t max|e_t| + 1e-9 (S = the real-number sum),
 //     so a hit has S > thr' = thr - delta, i.e. its DEFICIT sum_t (hi_t - e_t) < D = sum_t hi_t - thr'.
 // Deficits are quantised DOWN to v_t = floor(min(hi_t - e_t, D) / q), q = D / V, and stored as credits w_t = V - v_t
-// (unsigned 16 bit).  hit => sum_t v_t <= sum_t (hi_t - e_t)/q < V  =>  sum_t w_t >= X = (npair - 1) V + 1; an entry
-// with deficit >= D (-inf cells included) alone puts the sum at most at X - 1.  Pair row 0 also carries 32768 - X,
-// so "may be a hit" is bit 15 of the 16-bit sum.  V = 32767 / max(npair - 1, 1) keeps every sum below 65536 (two
-// motifs share a 32-bit word, a carry would corrupt the neighbour): 32768 - X + npair V = 32767 + V.
+// (unsigned, B = 16 or 10 bits).  hit => sum_t v_t <= sum_t (hi_t - e_t)/q < V  =>  sum_t w_t >= X = (npair - 1) V + 1;
+// an entry with deficit >= D (-inf cells included) alone puts the sum at most at X - 1.  Pair row 0 also carries
+// H - X with H = 2^(B-1), so "may be a hit" is bit B-1 of the B-bit sum.  V = (H - 1) / max(npair - 1, 1) keeps every sum
+// below 2^B (two 16-bit or three 10-bit credits share a 32-bit word, a carry would corrupt the neighbour):
+// H - X + npair V = H - 1 + V.  k_library uses B = 10 (twelve motifs per 16-byte table entry) for PFMs of up to 8 pair
+// rows, where V >= 73 levels per row still leave the slack at a few per cent of D, and B = 16 (eight per entry) beyond.
 // Integer adds are exact; the only slack is the rounding of the deficits (< npair * q in the score, one-sided).
 // A motif with +inf / NaN two-letter sums (background 0 for a letter the PFM uses) gets no prefilter: its row 0
 // is 32768 everywhere, every window goes to the exact pass.
@@ -39,11 +41,12 @@ struct LibPass {
 // Returns the one-sided slack of the prefilter in score units (0 when no window can pass, inf without prefilter).
 }  // namespace
 
-double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint16_t *out)
+double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint16_t *out, int bits)
 {
     std::fill(out, out + (size_t)npair * 16, (uint16_t)0);
-    if (thr == INFINITY) return 0.0;                      // nothing exceeds +inf: all credits 0, bit 15 never set
-    const int V = std::min(32767, 32767 / std::max(npair - 1, 1));
+    if (thr == INFINITY) return 0.0;                      // nothing exceeds +inf: all credits 0, the flag bit never set
+    const int half = 1 << (bits - 1);                     // the flag bit of a credit sum: 32768 (16-bit) or 512 (10-bit credits)
+    const int V = std::min(half - 1, (half - 1) / std::max(npair - 1, 1));
     const int X = (npair - 1) * V + 1;
     double sum_abs = 0.0, sum_hi = 0.0;
     std::vector<double> HI((size_t)npair, 0.0);
@@ -64,10 +67,10 @@ double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint
         sum_hi += HI[t];
     }
     if (special) {                                        // every window goes to the exact pass
-        for (int i = 0; i < 16; ++i) out[i] = 32768u;
+        for (int i = 0; i < 16; ++i) out[i] = (uint16_t)half;
         return INFINITY;
     }
-    for (int i = 0; i < 16; ++i) out[i] = (uint16_t)(32768 - X);
+    for (int i = 0; i < 16; ++i) out[i] = (uint16_t)(half - X);
     const double delta = 0x1p-23 * sum_abs + 1e-9;
     double D = sum_hi - (thr - delta);
     D += 1e-12 * (std::fabs(D) + std::fabs(sum_hi) + std::fabs(thr)) + 1e-300;       // the fp64 evaluation of D itself
@@ -142,12 +145,13 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
     const int npair = lib->npair;
     lib->pairsum.resize((size_t)n_motifs * npair * 16);
     for (int k = 0; k < n_motifs; ++k) pair_sums(letter_tables + (size_t)k * m * 8, m, lib->pairsum.data() + (size_t)k * npair * 16);
-    // passes: as many motif octets as the 160 KB of LDS hold next to the wave queues (the octet count of a pass is
+    // passes: as many motif groups as the 160 KB of LDS hold next to the wave queues (the group count of a pass is
     // a template parameter of the kernel, so it comes from a small supported set); full passes first, the rest last
-    const size_t per_motif = lib_motif_bytes(m, npair, lib->has_struct);
+    const int mpg = lib_mpg(lib->np_bucket);
+    const size_t per_group = lib_group_bytes(m, npair, lib->has_struct, lib->np_bucket);
     const size_t fixed = lib_queue_bytes(lib->np_bucket);
-    const int fit_octets = (int)((160 * 1024 - fixed - 64) / per_motif / 8);
-    const int ng_max = lib_pick_ng(lib->np_bucket, 1 << 20, fit_octets);
+    const int fit_groups = (int)((160 * 1024 - fixed - 64) / per_group);
+    const int ng_max = lib_pick_ng(lib->np_bucket, 1 << 20, fit_groups);
     if (ng_max < 1) {
         delete lib;
         return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "PFM too wide for the library kernel's LDS tables");
@@ -156,9 +160,9 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
     for (int base = 0; base < n_motifs;) {
         LibPass ps;
         ps.motif_base = base;
-        ps.n_real = std::min(n_motifs - base, ng_max * 8);
-        ps.ng = lib_pick_ng(lib->np_bucket, (ps.n_real + 7) / 8, ng_max);
-        ps.nmp = ps.ng * 8;
+        ps.n_real = std::min(n_motifs - base, ng_max * mpg);
+        ps.ng = lib_pick_ng(lib->np_bucket, (ps.n_real + mpg - 1) / mpg, ng_max);
+        ps.nmp = ps.ng * mpg;
         ps.pairs_off = pairs_elems;
         ps.letters_off = letters_elems;
         ps.pssm_off = pssm_elems;
@@ -212,13 +216,15 @@ void pfmscan_library_destroy(pfmscan_library *lib)
     delete lib;
 }
 
-int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack)
+int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq, int bits, uint16_t *credits, double *slack)
 {
     if (!letter_table || !credits || m < 1 || m > PFMSCAN_MAX_M || std::isnan(thr_seq)) return PFMSCAN_E_BADARG;
+    if (bits == 0) bits = lib_credit_bits(lib_np_bucket(m));             // what k_library uses at this width
+    if (bits != 10 && bits != 16) return PFMSCAN_E_BADARG;
     const int npair = (m + 1) / 2;
     std::vector<double> ps((size_t)npair * 16);
     pair_sums(letter_table, m, ps.data());
-    const double s = build_credits(ps.data(), npair, thr_seq, credits);
+    const double s = build_credits(ps.data(), npair, thr_seq, credits, bits);
     if (slack) *slack = s;
     return PFMSCAN_OK;
 }
@@ -258,9 +264,11 @@ static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const doub
     lib->h_thr.assign(lib->thr_elems, 0.0);
     lib->eps.assign((size_t)n, 0.0);
     std::vector<uint16_t> cr((size_t)npair * 16);
+    const int mpg = lib_mpg(lib->np_bucket), bits = lib_credit_bits(lib->np_bucket);
+    uint32_t *words = reinterpret_cast<uint32_t *>(lib->h_pairs.data());       // an entry = 4 dwords (16-byte aligned offsets)
     for (const LibPass &ps : lib->passes) {
         for (int l = 0; l < ps.nmp; ++l) {
-            const int g = l / 8, slot = l % 8;
+            const int g = l / mpg, slot = l % mpg;
             if (l >= ps.n_real) {                         // padding motif: all credits 0, never flagged
                 lib->h_thr[ps.thr_off + l] = INFINITY;
                 lib->h_thr[ps.thr_off + ps.nmp + l] = INFINITY;
@@ -269,10 +277,15 @@ static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const doub
             const int k = ps.motif_base + l;
             lib->h_thr[ps.thr_off + l] = thr_seq[k];
             lib->h_thr[ps.thr_off + ps.nmp + l] = lib->has_struct ? thr_struct[k] : -INFINITY;
-            lib->eps[k] = build_credits(lib->pairsum.data() + (size_t)k * npair * 16, npair, thr_seq[k], cr.data());
-            for (int t = 0; t < npair; ++t)               // kernel layout [pair row][octet][entry][motif of the octet]
-                for (int i = 0; i < 16; ++i)
-                    lib->h_pairs[ps.pairs_off + (((size_t)t * ps.ng + g) * 16 + i) * 8 + slot] = cr[t * 16 + i];
+            lib->eps[k] = build_credits(lib->pairsum.data() + (size_t)k * npair * 16, npair, thr_seq[k], cr.data(), bits);
+            for (int t = 0; t < npair; ++t)               // kernel layout [pair row][group][entry][4 dwords]
+                for (int i = 0; i < 16; ++i) {
+                    uint32_t *entry = words + ps.pairs_off / 2 + (((size_t)t * ps.ng + g) * 16 + i) * 4;
+                    if (mpg == 12)                        // motif 3 d + f of the group: bits 10 f .. 10 f + 9 of dword d
+                        entry[slot / 3] |= (uint32_t)cr[t * 16 + i] << (10 * (slot % 3));
+                    else                                  // motif 2 d + h: half h of dword d
+                        entry[slot / 2] |= (uint32_t)cr[t * 16 + i] << (16 * (slot % 2));
+                }
         }
     }
     HIP_TRY(ctx, hipMemcpyAsync(lib->d_pairs, lib->h_pairs.data(), lib->pairs_elems * 2, hipMemcpyHostToDevice, st));

@@ -31,10 +31,14 @@ def credit_sums(credits, codes, m):
     return tot
 
 
+@pytest.mark.parametrize("bits", [16, 10])
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("inf_frac", [0.0, 0.2])
-def test_prefilter_never_drops_a_hit(m, inf_frac):
+def test_prefilter_never_drops_a_hit(m, inf_frac, bits):
+    """bits = 16: two credits per dword (k_letters_cred, wide library PFMs); bits = 10: three per dword, the library
+    kernel's twelve-motifs-per-entry tables for widths up to 16"""
     rng = np.random.default_rng(31 * m + int(10 * inf_frac))
+    top, flag = (1 << bits) - 1, 1 << (bits - 1)
     n_letters = m + (m & 1)                            # an odd width's last pair also sees the letter AFTER the window
     codes = all_windows(n_letters)
     for trial in range(6):
@@ -49,10 +53,10 @@ def test_prefilter_never_drops_a_hit(m, inf_frac):
             thrs += [float(fin[int(q * (fin.size - 1))]) for q in (0.0, 0.5, 0.9, 0.99, 1.0)]            # ON scores
             thrs += [float(np.nextafter(np.float32(fin[int(0.9 * (fin.size - 1))]), np.float32(-np.inf)))]
         for thr in thrs:
-            credits, slack = _lib.credit_table(T, thr)
+            credits, slack = _lib.credit_table(T, thr, bits)
             tot = credit_sums(credits, codes, m)
-            assert tot.max() <= 65535, "a 16-bit sum would carry into the neighbouring motif"
-            flagged = (tot & 0x8000) != 0
+            assert tot.max() <= top, "a sum would carry into the neighbouring motif's field"
+            flagged = (tot & flag) != 0
             hit = f.astype(np.float64) > thr
             assert not (hit & ~flagged).any(), "prefilter dropped a hit (m=%d thr=%r)" % (m, thr)
             if np.isfinite(slack) and flagged.any():
@@ -71,21 +75,22 @@ def test_prefilter_disabled_for_plus_inf_cells():
     assert ((credit_sums(credits, codes, 4) & 0x8000) != 0).all()          # everything goes to the exact pass
 
 
-def test_wide_motifs_keep_sums_inside_16_bits():
+def test_wide_motifs_keep_sums_inside_their_fields():
     rng = np.random.default_rng(9)
-    for m in (12, 18, 33, 64):
+    for m, bits in ((12, 16), (12, 10), (16, 10), (9, 0), (18, 0), (18, 16), (33, 16), (64, 16)):
         T = np.full((m, 8), np.nan)
         T[:, :4] = rng.normal(0, 3, size=(m, 4))
+        used = bits or (10 if m <= 16 else 16)            # bits = 0: what k_library takes at this width
         for thr in (6.0, -50.0, 40.0):
-            credits, slack = _lib.credit_table(T, thr)
-            assert int(credits.max(axis=1).astype(np.int64).sum()) <= 65535
+            credits, slack = _lib.credit_table(T, thr, bits)
+            assert int(credits.max(axis=1).astype(np.int64).sum()) <= (1 << used) - 1
             # random windows: hits are never dropped
             codes = rng.integers(0, 4, size=(200000, m + (m & 1)))
             f = exact_scores(T, codes)
-            flagged = (credit_sums(credits, codes, m) & 0x8000) != 0
+            flagged = (credit_sums(credits, codes, m) & (1 << (used - 1))) != 0
             assert not ((f.astype(np.float64) > thr) & ~flagged).any()
             # best window of the motif: certainly kept when it is a hit
             best = np.argmax(T[:, :4], axis=1)[None, :]
             best = np.concatenate([best, np.zeros((1, m & 1), dtype=best.dtype)], axis=1)
             if float(exact_scores(T, best)[0]) > thr:
-                assert (credit_sums(credits, best, m) & 0x8000).all()
+                assert (credit_sums(credits, best, m) & (1 << (used - 1))).all()
