@@ -72,24 +72,16 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
     const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(profile) + p * 7;
     const f64x2 *P = reinterpret_cast<const f64x2 *>(pssm_lds) + mo;
     double score = 0.0;
-    for (int j0 = 0; j0 < m; j0 += 4) {
-        PROF_T val[28];
-        int base = j0;
-        if (m >= 4) {
-            base = j0 < m - 4 ? j0 : m - 4;
-            const PROF_T *r = prof + base * 7;
+    // rows [base, base + 4) of the window as 7 four-vectors; the last block of a width that is no multiple of 4 starts
+    // at m - 4 and skips the rows it shares with the block before
+    auto block_base = [&](int j0) { return j0 < m - 4 ? j0 : m - 4; };
+    auto fetch = [&](int j0, v4_t (&q)[7]) {
+        const PROF_T *r = prof + block_base(j0) * 7;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const v4_t q = *reinterpret_cast<const v4_t *>(r + 4 * k);
-                val[4 * k] = q[0];
-                val[4 * k + 1] = q[1];
-                val[4 * k + 2] = q[2];
-                val[4 * k + 3] = q[3];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
-        }
+        for (int k = 0; k < 7; ++k) q[k] = *reinterpret_cast<const v4_t *>(r + 4 * k);
+    };
+    auto rows = [&](int j0, const PROF_T (&val)[28]) {
+        const int base = m >= 4 ? block_base(j0) : j0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = base + u;
@@ -105,6 +97,38 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
                 d = fma((double)val[u * 7 + 6], p67.x, d);
                 score += lib_nan_to_num(d);
             }
+        }
+    };
+    auto unpack = [&](const v4_t (&q)[7], PROF_T (&val)[28]) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            val[4 * k] = q[k][0];
+            val[4 * k + 1] = q[k][1];
+            val[4 * k + 2] = q[k][2];
+            val[4 * k + 3] = q[k][3];
+        }
+    };
+    if (m < 4) {                                       // narrower than one block: element loads
+        PROF_T val[28];
+#pragma unroll
+        for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
+        rows(0, val);
+        return score;
+    }
+    // two blocks in flight: the loads of block j0 + 4 are issued before block j0 is scored, so a batch waits for the
+    // memory once, not once per block (the 16 waves of a CU are not enough to hide three round trips per batch)
+    v4_t qa[7], qb[7];
+    PROF_T val[28];
+    fetch(0, qa);
+    for (int j0 = 0; j0 < m; j0 += 8) {
+        const bool more1 = j0 + 4 < m, more2 = j0 + 8 < m;
+        if (more1) fetch(j0 + 4, qb);
+        unpack(qa, val);
+        rows(j0, val);
+        if (more1) {
+            if (more2) fetch(j0 + 8, qa);
+            unpack(qb, val);
+            rows(j0 + 4, val);
         }
     }
     return score;
@@ -147,10 +171,11 @@ __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const i
 //   8 motifs per entry (16-bit credits): p0 = the four sign BYTES of x, y (motifs 0..3), p1 = those of z, w (motifs 4..7)
 //     with the group g in bits 0-5 of p1;
 //   12 motifs per entry (10-bit credits, fields at bits 0 / 10 / 20 of a dword): p0 = bit (10 f + d) for motif 3 d + f,
-//     with the group g in bits 24-29.
+//     with the group g in bits 24-29; p1 = the window's letters (widths up to 16: two bits each), so that the exact pass
+//     starts from LDS alone instead of waiting for five scattered code loads.
 template <int MPG>
 __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const unsigned long long mk, const int qn, const int g,
-                                         const uint32_t relpos, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
+                                         const uint32_t relpos, const uint32_t cw, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     if (flag) {
         const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
@@ -158,6 +183,7 @@ __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const
         if constexpr (MPG == 12) {
             constexpr uint32_t M = 0x20080200u;
             q_p0[slot] = ((acc.x & M) >> 9) | ((acc.y & M) >> 8) | ((acc.z & M) >> 7) | ((acc.w & M) >> 6) | ((uint32_t)g << 24);
+            q_p1[slot] = cw;                            // the window's (up to 16) letters, two bits each: phase B reads no codes
         } else {
             const uint32_t p0 = __builtin_amdgcn_perm(acc.y, acc.x, 0x07050301u);
             const uint32_t p1 = __builtin_amdgcn_perm(acc.w, acc.z, 0x07050301u);
@@ -171,7 +197,7 @@ __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const
 // the queue has room; returns the first group that did NOT fit (NG when all did) -- from there the slow path takes
 // over after a drain.  A chunk brings one or two items per group at realistic thresholds, the queue takes >= 65.
 template <int K, int NG, int NP>
-__device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
+__device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos, const uint32_t cw,
                                                uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     int g_next = NG;
@@ -190,7 +216,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
             g_next = fits ? NG : g;
             qs = fits ? qs + n : qs;
             asm volatile("" : "+s"(qs), "+s"(g_next));
-            if (fits) lib_push<lib_mpg(NP)>(acc, flag, mk, at, g, relpos, q_pos, q_p0, q_p1);
+            if (fits) lib_push<lib_mpg(NP)>(acc, flag, mk, at, g, relpos, cw, q_pos, q_p0, q_p1);
         }
     }
     qn = qs;
@@ -200,7 +226,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 // Phase A, slow path: groups g .. NG-1 one by one (runtime table offset), stopping as soon as 64 items wait.
 // Needs qn < 64 on entry (a group brings at most 64 items, the queue holds LIB_QCAP >= 127).
 template <int K, int NG, int NP>
-__device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos,
+__device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos, const uint32_t cw,
                                                uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     int qs = __builtin_amdgcn_readfirstlane(qn);
@@ -210,7 +236,7 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
         if (mk) {
-            lib_push<lib_mpg(NP)>(acc, flag, mk, qs, g, relpos, q_pos, q_p0, q_p1);
+            lib_push<lib_mpg(NP)>(acc, flag, mk, qs, g, relpos, cw, q_pos, q_p0, q_p1);
             qs += __popcll(mk);
         }
         ++g;
@@ -222,17 +248,17 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
 // npair -> the K-row instantiation, over the pair counts of one width bucket (K = KLO .. NP)
 template <bool FAST, int K, int NG, int NP>
 __device__ __forceinline__ int lib_dispatch(const int npair, const int g, const lds_cptr (&rowp)[NP], int &qn,
-                                            const uint32_t relpos, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
+                                            const uint32_t relpos, const uint32_t cw, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
 {
     if constexpr (K >= NP) {
-        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, q_pos, q_p0, q_p1);
-        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, q_pos, q_p0, q_p1);
+        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
     } else {
         if (npair == K) {
-            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, q_pos, q_p0, q_p1);
-            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, q_pos, q_p0, q_p1);
+            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
         }
-        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, q_pos, q_p0, q_p1);
+        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
     }
 }
 
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const bool have = lane < cnt;
         const int idx = first + (have ? lane : 0);
         const uint32_t rel = q_pos[idx];
-        const uint32_t p0 = q_p0[idx], p1 = MPG == 12 ? 0u : q_p1[idx];
+        const uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
         // bits: one per flagged motif of the group; slot_of(bit) = its motif within the group
         //   8 per entry: byte b, bit 0 = motif b, bit 1 = motif 4 + b;   12 per entry: bit 10 f + d = motif 3 d + f
         uint32_t bits = !have ? 0u : (MPG == 12 ? (p0 & 0x00F03C0Fu) : (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u)));
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
                 if (MPG == 12) {
                     q_p0[slot] = bits | (g << 24);
+                    q_p1[slot] = p1;
                 } else {
                     q_p0[slot] = (bits & 0x01010101u) << 7;
                     q_p1[slot] = ((bits & 0x02020202u) << 6) | g;
@@ -317,9 +344,10 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         } else {
             requeued = 0;
         }
-        // the window's letters again (L2: the wave read them a few chunks ago); it has no foreign letter, or it would not be here
+        // the window's letters: from the item (12 motifs per entry), else read again (L2: the wave read them a few chunks
+        // ago); the window has no foreign letter, or it would not be here
         uint32_t w[NP / 2];
-        {
+        if (MPG != 12) {
             const int64_t al = p & ~(int64_t)3;
             uint32_t raw[NRAW];
 #pragma unroll
@@ -334,7 +362,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 #pragma unroll
         for (int j = 0; j < NP * 2; ++j) {
             if (j < m) {
-                const uint32_t c = (w[j >> 2] >> ((j & 3) * 8)) & 3u;
+                const uint32_t c = MPG == 12 ? (p1 >> (2 * j)) & 3u : (w[j >> 2] >> ((j & 3) * 8)) & 3u;
                 sc += L[(j * 4) * NMP + c * NMP];
             }
         }
@@ -390,7 +418,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 for (int k = 0; k < NRAW; ++k) raw[k] = lib_codes4(a.codes, al + 4 * k, n_pos);
             }
             lds_cptr rowp[NP];
-            uint32_t badbits = 0;
+            uint32_t badbits = 0, cw = 0;               // cw: the window's letters, two bits each (12 motifs per entry: m <= 16)
 #pragma unroll
             for (int k = 0; k < NP / 2; ++k) {
                 const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(lane & 3));
@@ -400,6 +428,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 badbits |= w & vm;
                 const uint32_t x = w & 0x03030303u;
                 const uint32_t y = x | (x >> 6);             // pair (b0,b1) in bits 0-3, pair (b2,b3) in bits 16-19
+                if (MPG == 12) cw |= ((y & 0xFu) | ((y >> 12) & 0xF0u)) << (8 * k);
                 rowp[2 * k] = pairs_lds + (2 * k) * (NG * 256) + ((y & 0xFu) << 4);
                 rowp[2 * k + 1] = pairs_lds + (2 * k + 1) * (NG * 256) + (((y >> 16) & 0xFu) << 4);
             }
@@ -410,14 +439,14 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (dead) rowp[0] = pairs_lds + pair_bytes;
 
             const uint32_t relpos = (uint32_t)(rel0 + lane);
-            int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, q_pos, q_p0, q_p1);
+            int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
             for (;;) {
                 while (qn >= 64) {                           // the top 64 items; the rest stays (LIFO)
                     dense(qn - 64, 64);
                     qn += requeued - 64;
                 }
                 if (g >= NG) break;
-                g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, q_pos, q_p0, q_p1);
+                g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
             }
         }
     }
