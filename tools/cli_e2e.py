@@ -75,8 +75,28 @@ if RBIG and BIGSTORE:
                      ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-q",
                       os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", thr,
                       "--profile-dtype", "float32", big, bigsd]))
+NLIB = int(os.environ.get("CLI_E2E_LIBRARY", "0"))          # a library of this many seq+struct PFM pairs (config 5's command line)
+if NLIB:
+    def write_library(path, letters, seed):
+        g = np.random.default_rng(seed)
+        with open(path, "w") as f:
+            for k in range(NLIB):
+                f.write("#RBP%03d\n#PO" % k + "".join("\t" + l for l in letters) + "\n")
+                for i, row in enumerate(g.dirichlet(np.full(len(letters), 0.5), size=12)):
+                    f.write(str(i) + "".join("\t" + str(float(x)) for x in row) + "\n")
+                f.write("\n")
+    lib_s, lib_t = os.path.join(d, "seq_lib.pfm"), os.path.join(d, "struct_lib.pfm")
+    write_library(lib_s, "ACGU", 1000)
+    write_library(lib_t, "EHTBLRM", 2000)
+    runs.append(("library: %d pairs, seq + struct (store) -m 6" % NLIB,
+                 ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", "--profile-dtype", "float32", fa, sd]))
+    runs.append(("library: %d seq PFMs -m 6" % NLIB, ["-p", lib_s, "-C", "0.01", "-u", "-m", "6", fa]))
+    if RBIG and BIGSTORE:
+        runs.append(("big library: %d pairs, seq + struct (store) -m 6" % NLIB,
+                     ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", "--profile-dtype", "float32", big, bigsd]))
 for name, argv in runs:
     nrec = RBIG if name.startswith("big") else R
+    nmot = NLIB if "library" in name else 1
     path = os.path.join(d, "out.tsv")
     with open(path, "w", encoding="utf-8", newline="") as out:
         prof = None
@@ -91,5 +111,5 @@ for name, argv in runs:
             prof.disable()
             pstats.Stats(prof, stream=sys.stdout).sort_stats("tottime").print_stats(12)
     rows = sum(1 for _ in open(path, "rb")) - 1
-    print("%-40s %.2f s   %d rows   %.3g windows/s   %.1f MB of table" % (name, dt, rows, nrec * (L - 17) / dt,
+    print("%-52s %.2f s   %d rows   %.3g motif-windows/s   %.1f MB of table" % (name, dt, rows, nmot * nrec * (L - 17) / dt,
                                                                          os.path.getsize(path) / 1e6))
