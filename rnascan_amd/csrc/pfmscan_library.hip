@@ -170,9 +170,10 @@ __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const i
 // ~1.3 items per group and chunk):
 //   8 motifs per entry (16-bit credits): p0 = the four sign BYTES of x, y (motifs 0..3), p1 = those of z, w (motifs 4..7)
 //     with the group g in bits 0-5 of p1;
-//   12 motifs per entry (10-bit credits, fields at bits 0 / 10 / 20 of a dword): p0 = bit (10 f + d) for motif 3 d + f,
-//     with the group g in bits 24-29; p1 = the window's letters (widths up to 16: two bits each), so that the exact pass
-//     starts from LDS alone instead of waiting for five scattered code loads.
+//   12 motifs per entry (10-bit credits, fields at bits 0 / 10 / 20 of a dword): p0 = the group g in bits 24-29 (and, for
+//     an item that went back to the queue, bit 31 + the flags still to do: bit (10 f + d) for motif 3 d + f);
+//     p1 = the window's letters (widths up to 16: two bits each), so that the exact pass starts from LDS alone instead
+//     of waiting for five scattered code loads.
 template <int MPG>
 __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const unsigned long long mk, const int qn, const int g,
                                          const uint32_t relpos, const uint32_t cw, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
@@ -181,9 +182,11 @@ __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const
         const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
         q_pos[slot] = relpos;
         if constexpr (MPG == 12) {
-            constexpr uint32_t M = 0x20080200u;
-            q_p0[slot] = ((acc.x & M) >> 9) | ((acc.y & M) >> 8) | ((acc.z & M) >> 7) | ((acc.w & M) >> 6) | ((uint32_t)g << 24);
-            q_p1[slot] = cw;                            // the window's (up to 16) letters, two bits each: phase B reads no codes
+            // nine groups out of ten push something at C5's candidate rate: the push is the common path, so it stores what
+            // it has -- the group and the window's letters (two bits each) -- and phase B, 64 items at a time, looks the
+            // item's credits up again to see WHICH motifs were flagged
+            q_p0[slot] = (uint32_t)g << 24;
+            q_p1[slot] = cw;
         } else {
             const uint32_t p0 = __builtin_amdgcn_perm(acc.y, acc.x, 0x07050301u);
             const uint32_t p1 = __builtin_amdgcn_perm(acc.w, acc.z, 0x07050301u);
@@ -319,8 +322,26 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
         // bits: one per flagged motif of the group; slot_of(bit) = its motif within the group
         //   8 per entry: byte b, bit 0 = motif b, bit 1 = motif 4 + b;   12 per entry: bit 10 f + d = motif 3 d + f
-        uint32_t bits = !have ? 0u : (MPG == 12 ? (p0 & 0x00F03C0Fu) : (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u)));
-        const uint32_t g = MPG == 12 ? (p0 >> 24) : (p1 & 0x3Fu);
+        const uint32_t g = MPG == 12 ? ((p0 >> 24) & 0x3Fu) : (p1 & 0x3Fu);
+        uint32_t bits;
+        if (MPG == 12) {
+            // a fresh item: its group's credit sums once more (npair look-ups for 64 items at once), flags as below;
+            // an item that came back carries what is left of them
+            u32x4 acc = {0u, 0u, 0u, 0u};
+            const lds_cptr ent = pairs_lds + g * 256;
+            for (int t = 0; t < npair; ++t) {
+                const u32x4 r = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(ent + t * (NG * 256) + (((p1 >> (4 * t)) & 0xFu) << 4));
+                acc.x += r.x;
+                acc.y += r.y;
+                acc.z += r.z;
+                acc.w += r.w;
+            }
+            constexpr uint32_t M = 0x20080200u;
+            const uint32_t fresh = ((acc.x & M) >> 9) | ((acc.y & M) >> 8) | ((acc.z & M) >> 7) | ((acc.w & M) >> 6);
+            bits = !have ? 0u : ((p0 & 0x80000000u) ? (p0 & 0x00F03C0Fu) : fresh);
+        } else {
+            bits = !have ? 0u : (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u));
+        }
         const int64_t p = a.pos_base + (int64_t)rel;
         const bool act = bits != 0;
         const int q = act ? __builtin_ctz(bits) : 0;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
                 if (MPG == 12) {
-                    q_p0[slot] = bits | (g << 24);
+                    q_p0[slot] = bits | (g << 24) | 0x80000000u;
                     q_p1[slot] = p1;
                 } else {
                     q_p0[slot] = (bits & 0x01010101u) << 7;
