@@ -305,6 +305,17 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
                          const int64_t *n_letters, int64_t lo, int64_t hi, const uint8_t *lut256,
                          int separator, uint8_t *codes, int64_t *offsets, int n_threads);
 
+/* Averaged-structure profile text (written by rnascan/pfmutil.py:61-87: a header line, then one row per position:
+ * <position> TAB <n_cols numbers>) -> float64 [n_rows][n_cols], the first column dropped, exactly as the reference reads
+ * it: `pd.read_table` then `del struct['PO']` (rnascan/rnascan.py:296-297).  pandas' default converter is NOT correctly
+ * rounded (at most 17 digits, leading zeros included, then one multiplication or division by a power of ten; about
+ * half of all 17-digit reprs come out one ulp off) and the reference computes with those values, so that converter is
+ * restated here bit for bit (tests/test_ingest.py compares millions of fields with pandas itself).  The header line is
+ * skipped (the caller reads the column letters from it).  PFMSCAN_E_BADSHAPE: something only pandas should judge (blank
+ * lines, ragged rows, nan / inf tokens, quotes): parse the file with pandas instead.  PFMSCAN_E_CAPACITY: *n_rows set. */
+int pfmscan_profile_parse(const char *buf, int64_t n, int n_cols, int64_t capacity_rows,
+                          double *out, int64_t *n_rows);
+
 /* Hit columns -> the bytes `DataFrame.to_csv(sep='\t', index=False)` writes for them (rnascan/rnascan.py:555-567,
  * Match_ID :329-332), without building the table: one descriptor per column, rows formatted in parallel.
  *   CONST    data = bytes, width = their length (the same field in every row)

@@ -33,7 +33,7 @@ SYMBOLS = [
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
-    "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format",
+    "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -126,6 +126,7 @@ def load():
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
+    L.pfmscan_profile_parse.argtypes = [ctypes.c_char_p, i64, i32, i64, vp, ctypes.POINTER(i64)]
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i32), i32]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
@@ -228,6 +229,21 @@ def fasta_encode(buf, seq_off, seq_end, n_letters, lo, hi, lut, separator=SEP, t
         if rc != OK:
             _raise(L, None, rc)
     return codes, offsets
+
+
+def profile_parse(data, n_cols):
+    """bytes of an averaged-structure profile file -> float64 [n_rows][n_cols] (first column dropped, header skipped), the
+    numbers converted exactly as pandas' read_table converts them; None when the file is one for pandas to judge"""
+    L = load()
+    cap = data.count(b"\n") + 1
+    out = np.empty((cap, n_cols), dtype=np.float64)
+    k = ctypes.c_int64(0)
+    rc = L.pfmscan_profile_parse(data, len(data), int(n_cols), cap, _ptr(out), ctypes.byref(k))
+    if rc == E_BADSHAPE:
+        return None
+    if rc != OK:
+        _raise(L, None, rc)
+    return out[:k.value]
 
 
 TSV_MAX_PIECES = 16

@@ -149,10 +149,8 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         weights = [os.path.getsize(path) // 64 + 1 for _, path in files]
 
         def scan_files(part):
-            named = []
-            for sid, path in part:
-                file_letters, prof = fasta.read_profile(path)
-                named.append((sid, file_letters, prof))
+            parsed = fasta.read_profiles([path for _, path in part])           # the files of the batch, on all cores
+            named = [(sid, file_letters, prof) for (sid, _), (file_letters, prof) in zip(part, parsed)]
             return scanner.scan_profiles(engine, named, pssm, args.minscore, args.pairing, ptype, compact)
 
         df = shard.scan_sharded(files, weights, scan_files, rank, world, dist, sink=sink)
@@ -281,6 +279,11 @@ def main(argv=None, engine=None, out=None):
                     file_letters, prof = fasta.read_profile(path)
                     out.append((sid, file_letters, prof))
                 return out
+
+            def load_many(ids):
+                todo = [(sid, path) for sid in ids for path in where.get(sid, [])]
+                parsed = fasta.read_profiles([path for _, path in todo])        # the batch's files on all cores
+                return [(sid, fl, prof) for (sid, _), (fl, prof) in zip(todo, parsed)]
         if n_prof == 0:
             raise IOError("No averaged structure files found")
         fasta.eprint("Processed %d sequences" % n_prof)
@@ -298,12 +301,12 @@ def main(argv=None, engine=None, out=None):
                 if at[0] >= 0 and at == list(range(at[0], at[0] + len(at))):
                     prepacked = (ids, ps.letters, ps.stream(at[0], at[0] + len(at)))
             if prepacked is None:
-                named = [t for rid in ids for t in load(rid)]
+                named = load_many(ids) if ps is None else [t for rid in ids for t in load(rid)]
             df = scanner.scan_combined(eng, part, named, seq_pssm, struct_pssm, args.minscore, args.pairing, ptype,
                                        columns=streaming, prepacked=prepacked)
             if df is None:
                 if named is None:
-                    named = [t for rid in ids for t in load(rid)]
+                    named = load_many(ids) if ps is None else [t for rid in ids for t in load(rid)]
                 df = scanner.combine(scanner.scan_records(eng, part, seq_pssm, fasta.RNA, args.minscore),
                                      scanner.scan_profiles(eng, named, struct_pssm, args.minscore, args.pairing, ptype))
                 df = df[scanner.COMBINED_COLUMNS]
@@ -313,7 +316,7 @@ def main(argv=None, engine=None, out=None):
             final = shard.scan_sharded(recs, recs.lengths, scan_pairs, rank, world, dist,
                                        sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
         else:                                  # duplicate ids join across records: two whole tables + join
-            named = [t for sid in where for t in load(sid)]
+            named = load_many(list(where)) if ps is None else [t for sid in where for t in load(sid)]
             seq_results = shard.scan_sharded(
                 recs, recs.lengths,
                 lambda part: scanner.scan_records(eng, part, seq_pssm, fasta.RNA, args.minscore), rank, world, dist)

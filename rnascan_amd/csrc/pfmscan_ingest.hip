@@ -326,6 +326,135 @@ int pfmscan_fasta_encode(const uint8_t *buf, const int64_t *seq_off, const int64
     return PFMSCAN_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// pandas' default float converter of read_table's C engine ("high" precision: precise_xstrtod, pandas >= 1.2) restated:
+// at most 17 digits INCLUDING leading zeros are accumulated in a double, the rest only move the exponent, then ONE
+// multiplication or division by an exactly represented power of ten.  Not correctly rounded (about half of all 17-digit
+// reprs come out one ulp off), which is exactly why it is restated: the reference reads its profiles with
+// pd.read_table (rnascan.py:296) and computes with these values.  Returns false on a token it does not take
+// (the caller then leaves the file to pandas).
+const double POW10[] = {
+    1e0,   1e1,   1e2,   1e3,   1e4,   1e5,   1e6,   1e7,   1e8,   1e9,   1e10,  1e11,  1e12,  1e13,  1e14,  1e15,  1e16,  1e17,  1e18,  1e19,
+    1e20,  1e21,  1e22,  1e23,  1e24,  1e25,  1e26,  1e27,  1e28,  1e29,  1e30,  1e31,  1e32,  1e33,  1e34,  1e35,  1e36,  1e37,  1e38,  1e39,
+    1e40,  1e41,  1e42,  1e43,  1e44,  1e45,  1e46,  1e47,  1e48,  1e49,  1e50,  1e51,  1e52,  1e53,  1e54,  1e55,  1e56,  1e57,  1e58,  1e59,
+    1e60,  1e61,  1e62,  1e63,  1e64,  1e65,  1e66,  1e67,  1e68,  1e69,  1e70,  1e71,  1e72,  1e73,  1e74,  1e75,  1e76,  1e77,  1e78,  1e79,
+    1e80,  1e81,  1e82,  1e83,  1e84,  1e85,  1e86,  1e87,  1e88,  1e89,  1e90,  1e91,  1e92,  1e93,  1e94,  1e95,  1e96,  1e97,  1e98,  1e99,
+    1e100, 1e101, 1e102, 1e103, 1e104, 1e105, 1e106, 1e107, 1e108, 1e109, 1e110, 1e111, 1e112, 1e113, 1e114, 1e115, 1e116, 1e117, 1e118, 1e119,
+    1e120, 1e121, 1e122, 1e123, 1e124, 1e125, 1e126, 1e127, 1e128, 1e129, 1e130, 1e131, 1e132, 1e133, 1e134, 1e135, 1e136, 1e137, 1e138, 1e139,
+    1e140, 1e141, 1e142, 1e143, 1e144, 1e145, 1e146, 1e147, 1e148, 1e149, 1e150, 1e151, 1e152, 1e153, 1e154, 1e155, 1e156, 1e157, 1e158, 1e159,
+    1e160, 1e161, 1e162, 1e163, 1e164, 1e165, 1e166, 1e167, 1e168, 1e169, 1e170, 1e171, 1e172, 1e173, 1e174, 1e175, 1e176, 1e177, 1e178, 1e179,
+    1e180, 1e181, 1e182, 1e183, 1e184, 1e185, 1e186, 1e187, 1e188, 1e189, 1e190, 1e191, 1e192, 1e193, 1e194, 1e195, 1e196, 1e197, 1e198, 1e199,
+    1e200, 1e201, 1e202, 1e203, 1e204, 1e205, 1e206, 1e207, 1e208, 1e209, 1e210, 1e211, 1e212, 1e213, 1e214, 1e215, 1e216, 1e217, 1e218, 1e219,
+    1e220, 1e221, 1e222, 1e223, 1e224, 1e225, 1e226, 1e227, 1e228, 1e229, 1e230, 1e231, 1e232, 1e233, 1e234, 1e235, 1e236, 1e237, 1e238, 1e239,
+    1e240, 1e241, 1e242, 1e243, 1e244, 1e245, 1e246, 1e247, 1e248, 1e249, 1e250, 1e251, 1e252, 1e253, 1e254, 1e255, 1e256, 1e257, 1e258, 1e259,
+    1e260, 1e261, 1e262, 1e263, 1e264, 1e265, 1e266, 1e267, 1e268, 1e269, 1e270, 1e271, 1e272, 1e273, 1e274, 1e275, 1e276, 1e277, 1e278, 1e279,
+    1e280, 1e281, 1e282, 1e283, 1e284, 1e285, 1e286, 1e287, 1e288, 1e289, 1e290, 1e291, 1e292, 1e293, 1e294, 1e295, 1e296, 1e297, 1e298, 1e299,
+    1e300, 1e301, 1e302, 1e303, 1e304, 1e305, 1e306, 1e307, 1e308};
+
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+
+bool pandas_float(const char *p, const char *end, double *out)
+{
+    bool negative = false;
+    if (p < end && (*p == '-' || *p == '+')) negative = *p++ == '-';
+    double number = 0.0;
+    int exponent = 0, num_digits = 0, num_decimals = 0;
+    const int max_digits = 17;
+    while (p < end && is_digit(*p)) {
+        if (num_digits < max_digits) {
+            number = number * 10. + (*p - '0');
+            ++num_digits;
+        } else {
+            ++exponent;
+        }
+        ++p;
+    }
+    if (p < end && *p == '.') {
+        ++p;
+        while (num_digits < max_digits && p < end && is_digit(*p)) {
+            number = number * 10. + (*p - '0');
+            ++p;
+            ++num_digits;
+            ++num_decimals;
+        }
+        if (num_digits >= max_digits)
+            while (p < end && is_digit(*p)) ++p;
+        exponent -= num_decimals;
+    }
+    if (num_digits == 0) return false;
+    if (negative) number = -number;
+    if (p < end && (*p == 'e' || *p == 'E')) {
+        ++p;
+        bool eneg = false;
+        if (p < end && (*p == '-' || *p == '+')) eneg = *p++ == '-';
+        int nd = 0, n = 0;
+        while (nd < max_digits && p < end && is_digit(*p)) {
+            n = n * 10 + (*p - '0');
+            ++nd;
+            ++p;
+        }
+        if (nd == 0) return false;
+        exponent += eneg ? -n : n;
+    }
+    if (p != end) return false;                       // anything else (nan, inf, blanks, thousands separators): pandas' business
+    if (exponent > 308) return false;
+    if (exponent > 0)
+        number *= POW10[exponent];
+    else if (exponent < -308) {
+        if (exponent < -616)
+            number = 0.;
+        else {
+            number /= POW10[-308 - exponent];
+            number /= POW10[308];
+        }
+    } else
+        number /= POW10[-exponent];
+    if (std::isinf(number)) return false;
+    *out = number;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int pfmscan_profile_parse(const char *buf, int64_t n, int n_cols, int64_t capacity_rows, double *out, int64_t *n_rows)
+{
+    if ((!buf && n > 0) || n < 0 || n_cols < 1 || capacity_rows < 0 || !n_rows || (!out && capacity_rows > 0))
+        return fail(nullptr, PFMSCAN_E_BADARG, "profile_parse: bad argument");
+    // rows after the header line: <first column, dropped> TAB value x n_cols; LF or CRLF; nothing else
+    int64_t pos = 0, rows = 0;
+    const char *nl = static_cast<const char *>(std::memchr(buf, '\n', (size_t)n));
+    pos = nl ? (nl - buf) + 1 : n;                      // the header is the caller's (it holds the column letters)
+    while (pos < n) {
+        nl = static_cast<const char *>(std::memchr(buf + pos, '\n', (size_t)(n - pos)));
+        int64_t e = nl ? nl - buf : n;
+        const int64_t next = nl ? e + 1 : n;
+        if (e > pos && buf[e - 1] == '\r') --e;
+        if (e == pos) return fail(nullptr, PFMSCAN_E_BADSHAPE, "profile_parse: empty line");     // pandas skips blank lines: leave it to pandas
+        const char *p = buf + pos, *end = buf + e;
+        const char *tab = static_cast<const char *>(std::memchr(p, '\t', (size_t)(end - p)));
+        if (!tab) return fail(nullptr, PFMSCAN_E_BADSHAPE, "profile_parse: a row without fields");
+        p = tab + 1;
+        for (int c = 0; c < n_cols; ++c) {
+            const char *q = c + 1 < n_cols ? static_cast<const char *>(std::memchr(p, '\t', (size_t)(end - p))) : end;
+            if (!q) return fail(nullptr, PFMSCAN_E_BADSHAPE, "profile_parse: too few fields in a row");
+            double v;
+            if (!pandas_float(p, q, &v)) return fail(nullptr, PFMSCAN_E_BADSHAPE, "profile_parse: a field that is no plain number");
+            if (rows < capacity_rows) out[rows * n_cols + c] = v;
+            p = q + 1;
+        }
+        ++rows;
+        pos = next;
+    }
+    *n_rows = rows;
+    if (rows > capacity_rows) return fail(nullptr, PFMSCAN_E_CAPACITY, "profile_parse: more rows than capacity");
+    return PFMSCAN_OK;
+}
+
+extern "C" {
+
 int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_rows, int64_t first_match_id, char *out,
                        int64_t capacity, int64_t *need, int64_t *pieces, int *n_pieces, int n_threads)
 {

@@ -349,10 +349,8 @@ def scan_profile_dir(engine, directory, pssm, minscore, pairing="aligned", profi
     files = fasta.list_profiles(directory)
     if len(files) == 0:
         raise IOError("No averaged structure files found")
-    named = []
-    for sid, path in files:
-        letters, prof = fasta.read_profile(path)
-        named.append((sid, letters, prof))
+    parsed = fasta.read_profiles([path for _, path in files])
+    named = [(sid, letters, prof) for (sid, _), (letters, prof) in zip(files, parsed)]
     df = scan_profiles(engine, named, pssm, minscore, pairing, profile_dtype)
     fasta.eprint("Processed %d sequences" % len(named))
     return df
@@ -495,8 +493,6 @@ def load_profile_dir(directory):
     from . import store
     if store.is_store(directory):
         return store.ProfileStore(directory).named()
-    named = []
-    for sid, path in fasta.list_profiles(directory):
-        letters, prof = fasta.read_profile(path)
-        named.append((sid, letters, prof))
-    return named
+    files = fasta.list_profiles(directory)
+    parsed = fasta.read_profiles([path for _, path in files])
+    return [(sid, letters, prof) for (sid, _), (letters, prof) in zip(files, parsed)]

@@ -251,3 +251,84 @@ def test_index_of_very_short_records_takes_the_exact_count_retry():
     ix = _lib.fasta_index(buf)
     assert ix[0].size == 5000 and ix[4].tolist() == [2] * 5000
     assert data[ix[0][4999]:ix[0][4999] + ix[1][4999]] == b"r4999"
+
+
+def _pandas_profile(path):
+    df = pd.read_table(path)
+    if "PO" in df.columns:
+        del df["PO"]
+    else:
+        df = df.iloc[:, 1:]
+    return [str(c) for c in df.columns], df.to_numpy(dtype=np.float64).reshape(-1, len(df.columns))
+
+
+def _write_profile(path, values, eol="\n", fmt=repr, header="PO\t" + "\t".join("BEHLMRT")):
+    with open(path, "w", newline="") as f:
+        f.write(header + eol)
+        for i, row in enumerate(values):
+            f.write(str(i) + "".join("\t" + fmt(float(v)) for v in row) + eol)
+
+
+def test_native_profile_parser_is_pandas_bit_for_bit(tmp_path):
+    """the reference reads its profiles with pd.read_table (rnascan.py:296-297), whose default float converter is not
+    correctly rounded; pfmscan_profile_parse restates that converter: every field must come out with pandas' bits"""
+    from conftest import DATA_DIR
+    rng = np.random.default_rng(17)
+    cases = {
+        "dirichlet": rng.dirichlet(np.full(7, 0.3), size=30000),
+        "uniform": rng.random((30000, 7)),
+        "tiny": 10.0 ** rng.uniform(-320, -3, size=(20000, 7)),
+        "huge": 10.0 ** rng.uniform(3, 300, size=(20000, 7)) * rng.choice([-1.0, 1.0], size=(20000, 7)),
+        "short": np.round(rng.random((5000, 7)), 3),
+        "ints": rng.integers(0, 3, size=(5000, 7)).astype(float),
+    }
+    differs_from_float = 0
+    for name, x in cases.items():
+        for eol in ("\n", "\r\n"):
+            path = str(tmp_path / (name + ".txt"))
+            _write_profile(path, x, eol)
+            letters, got = fasta.read_profile(path)
+            want_letters, want = _pandas_profile(path)
+            assert letters == want_letters == list("BEHLMRT")
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64)), name
+            differs_from_float += int((want != x).sum())
+    assert differs_from_float > 100000            # the converter IS different from float(): that is what is being matched
+    path = os.path.join(DATA_DIR, "HIST2H3C_3p_end_structure.txt")      # the reference's own example profile
+    letters, got = fasta.read_profile(path)
+    want_letters, want = _pandas_profile(path)
+    assert letters == want_letters and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    data = open(path, "rb").read()
+    assert _lib.profile_parse(data, len(letters)) is not None             # and it did go through the native parser
+
+
+def test_unusual_profile_files_are_left_to_pandas(tmp_path):
+    x = np.random.default_rng(3).random((50, 7))
+    odd = {
+        "nan token": lambda p: _write_profile(p, x, fmt=lambda v: "nan" if v < 0.05 else repr(v)),
+        "blank line": lambda p: (_write_profile(p, x), open(p, "a").write("\n\n")),
+        "no PO header": lambda p: _write_profile(p, x, header="idx\t" + "\t".join("BEHLMRT")),
+        "exponent forms": lambda p: _write_profile(p, x, fmt=lambda v: "%.6E" % v),
+        "plus signs": lambda p: _write_profile(p, x, fmt=lambda v: "+" + repr(v)),
+    }
+    for name, write in odd.items():
+        path = str(tmp_path / "odd.txt")
+        write(path)
+        letters, got = fasta.read_profile(path)
+        want_letters, want = _pandas_profile(path)
+        assert letters == want_letters, name
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), name
+    ragged = str(tmp_path / "ragged.txt")
+    _write_profile(ragged, x)
+    with open(ragged, "a") as f:
+        f.write("50\t0.1\t0.2\n")
+    assert _lib.profile_parse(open(ragged, "rb").read(), 7) is None
+    # a batch of files on the thread pool: same results, same order
+    paths = []
+    for k in range(12):
+        p = str(tmp_path / ("structure.r%d.txt" % k))
+        _write_profile(p, np.random.default_rng(k).dirichlet(np.full(7, 0.3), size=10 + 7 * k))
+        paths.append(p)
+    many = fasta.read_profiles(paths, threads=4)
+    for p, (letters, prof) in zip(paths, many):
+        want_letters, want = _pandas_profile(p)
+        assert letters == want_letters and np.array_equal(prof.view(np.uint64), want.view(np.uint64))

@@ -75,6 +75,27 @@ if RBIG and BIGSTORE:
                      ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-q",
                       os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", thr,
                       "--profile-dtype", "float32", big, bigsd]))
+NDIR = int(os.environ.get("CLI_E2E_DIR", "0"))               # a directory of this many structure.<id>.txt files (the reference's own
+if NDIR:                                                     # input format) beside a FASTA of the same records, 1000 nt each
+    LD = 1000
+    dd = os.path.join(d, "avgdir")
+    os.makedirs(dd)
+    dfa = os.path.join(d, "dir.fa")
+    t1 = time.time()
+    with open(dfa, "wb") as f:
+        for i in range(NDIR):
+            f.write(b">d%d\n" % i + letters[rng.integers(0, 4, size=LD)].tobytes() + b"\n")
+            p = rng.dirichlet(np.full(7, 0.3), size=LD)
+            with open(os.path.join(dd, "structure.d%d.txt" % i), "w") as g:
+                g.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+                g.write("".join("%d\t%s\n" % (j, "\t".join(map(repr, row))) for j, row in enumerate(p.tolist())))
+    print("directory of %d profile files written in %.1f s" % (NDIR, time.time() - t1), file=sys.stderr)
+    for parser in ("native", "pandas"):
+        runs.append(("directory (%s parser): struct only, %d files x %d rows" % (parser, NDIR, LD),
+                     ["-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", dd]))
+        runs.append(("directory (%s parser): seq + struct" % parser,
+                     ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-q",
+                      os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", "0", dfa, dd]))
 NLIB = int(os.environ.get("CLI_E2E_LIBRARY", "0"))          # a library of this many seq+struct PFM pairs (config 5's command line)
 if NLIB:
     def write_library(path, letters, seed):
@@ -97,6 +118,9 @@ if NLIB:
 for name, argv in runs:
     nrec = RBIG if name.startswith("big") else R
     nmot = NLIB if "library" in name else 1
+    if name.startswith("directory"):
+        os.environ["RNASCAN_PROFILE_PARSER"] = "pandas" if "pandas" in name else "native"
+        nrec = NDIR / 3.0                                  # 1000-nt records: a third of the default record in windows
     path = os.path.join(d, "out.tsv")
     with open(path, "w", encoding="utf-8", newline="") as out:
         prof = None
