@@ -275,12 +275,12 @@ def test_native_profile_parser_is_pandas_bit_for_bit(tmp_path):
     from conftest import DATA_DIR
     rng = np.random.default_rng(17)
     cases = {
-        "dirichlet": rng.dirichlet(np.full(7, 0.3), size=30000),
-        "uniform": rng.random((30000, 7)),
-        "tiny": 10.0 ** rng.uniform(-320, -3, size=(20000, 7)),
-        "huge": 10.0 ** rng.uniform(3, 300, size=(20000, 7)) * rng.choice([-1.0, 1.0], size=(20000, 7)),
-        "short": np.round(rng.random((5000, 7)), 3),
-        "ints": rng.integers(0, 3, size=(5000, 7)).astype(float),
+        "dirichlet": rng.dirichlet(np.full(7, 0.3), size=8000),
+        "uniform": rng.random((8000, 7)),
+        "tiny": 10.0 ** rng.uniform(-320, -3, size=(5000, 7)),
+        "huge": 10.0 ** rng.uniform(3, 300, size=(5000, 7)) * rng.choice([-1.0, 1.0], size=(5000, 7)),
+        "short": np.round(rng.random((2000, 7)), 3),
+        "ints": rng.integers(0, 3, size=(2000, 7)).astype(float),
     }
     differs_from_float = 0
     for name, x in cases.items():
@@ -292,7 +292,7 @@ def test_native_profile_parser_is_pandas_bit_for_bit(tmp_path):
             assert letters == want_letters == list("BEHLMRT")
             assert got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64)), name
             differs_from_float += int((want != x).sum())
-    assert differs_from_float > 100000            # the converter IS different from float(): that is what is being matched
+    assert differs_from_float > 30000             # the converter IS different from float(): that is what is being matched
     path = os.path.join(DATA_DIR, "HIST2H3C_3p_end_structure.txt")      # the reference's own example profile
     letters, got = fasta.read_profile(path)
     want_letters, want = _pandas_profile(path)
