@@ -425,7 +425,7 @@ extern "C" int pfmscan_profile_parse(const char *buf, int64_t n, int n_cols, int
         return fail(nullptr, PFMSCAN_E_BADARG, "profile_parse: bad argument");
     // rows after the header line: <first column, dropped> TAB value x n_cols; LF or CRLF; nothing else
     int64_t pos = 0, rows = 0;
-    const char *nl = static_cast<const char *>(std::memchr(buf, '\n', (size_t)n));
+    const char *nl = n ? static_cast<const char *>(std::memchr(buf, '\n', (size_t)n)) : nullptr;
     pos = nl ? (nl - buf) + 1 : n;                      // the header is the caller's (it holds the column letters)
     while (pos < n) {
         nl = static_cast<const char *>(std::memchr(buf + pos, '\n', (size_t)(n - pos)));

@@ -332,3 +332,33 @@ def test_unusual_profile_files_are_left_to_pandas(tmp_path):
     for p, (letters, prof) in zip(paths, many):
         want_letters, want = _pandas_profile(p)
         assert letters == want_letters and np.array_equal(prof.view(np.uint64), want.view(np.uint64))
+
+
+def test_ingest_under_sanitizers(tmp_path):
+    """the host-only native code (pfmscan_ingest.hip has no device code) compiled with g++ -fsanitize=address,undefined
+    and driven with random bytes in exact-size heap buffers (tests/c/fuzz_ingest.cpp): no overread, no overflow, no UB"""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    src = open(os.path.join(root, "rnascan_amd", "csrc", "pfmscan_ingest.hip")).read()
+    assert '#include "pfmscan_ctx.hpp"' in src
+    src = src.replace('#include "pfmscan_ctx.hpp"',
+                      '#include <cstdint>\n#include <string>\n#include "pfmscan.h"\n'
+                      'namespace pfmscan { int fail(pfmscan_ctx *ctx, int code, const std::string &msg); }')
+    (tmp_path / "ingest.cpp").write_text(src)
+    (tmp_path / "stub.cpp").write_text('#include <string>\nstruct pfmscan_ctx;\n'
+                                       'namespace pfmscan { int fail(pfmscan_ctx *, int code, const std::string &) { return code; } }\n')
+    exe = str(tmp_path / "fuzz")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + os.path.join(root, "include"), "-pthread", os.path.join(here, "c", "fuzz_ingest.cpp"),
+           str(tmp_path / "ingest.cpp"), str(tmp_path / "stub.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert built.returncode == 0, built.stderr[-2000:]
+    run = subprocess.run([exe, "4000"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and run.stdout.strip().startswith("ok"), (run.stdout + run.stderr)[-3000:]
