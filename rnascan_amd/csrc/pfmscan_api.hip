@@ -193,7 +193,7 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
             }
             // rounding of the entries + of the fp32 adds + of the exact score's float cast <= ~4e-6 * bound at 32 pairs
             mo->pair_eps = bound * 0x1p-17 + 1e-30;
-            if (four && m <= 16) {
+            if (four && m <= 32) {
                 pair_sums(letter_table, m, mo->h_pairsum);
                 mo->has_pairsum = true;
             }

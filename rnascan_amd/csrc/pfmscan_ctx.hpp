@@ -10,7 +10,7 @@ struct pfmscan_motif {
     double *d_letters = nullptr;   // [m][8]
     float *d_pairs = nullptr;      // [(m+1)/2][16] two-letter fp32 sums (4-letter alphabets only), see k_letters_pre
     double pair_eps = 0.0;
-    double h_pairsum[8 * 16];      // exact two-letter sums (m <= 16, 4-letter alphabets): operand of the integer prefilter
+    double h_pairsum[16 * 16];     // exact two-letter sums (m <= 32, 4-letter alphabets): operand of the integer prefilter
     bool has_pairsum = false;
     double *d_struct = nullptr;    // [m][7]
     int m = 0;

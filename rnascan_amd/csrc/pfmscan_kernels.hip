@@ -519,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
 
 // ---------------------------------------------------------------------------
 // k_letters_cred -- k_letters_pre with the INTEGER prefilter of the library kernel, keyed by stream position.
-// (PFMs up to width 16 over a 4-letter alphabet with a finite threshold)
+// (PFMs up to width 32 over a 4-letter alphabet with a finite threshold)
 //
 // k_letters_pre spends its time on ceil(m/2) four-byte look-ups and as many fp32 adds per window, plus the index
 // arithmetic of each.  Here the two-letter table is turned around: ONE entry per letter pair holds that pair's
@@ -537,10 +537,10 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
 // cast, strict compare -- one survivor per lane.  Hits: k_letters_pre's LDS hit queues, one returning atomic per flush.
 // ---------------------------------------------------------------------------
 struct CredTable {
-    uint32_t d[16][4];                                // [letter pair c0 | c1 << 2][row pair j]
+    uint32_t d[16][8];                                // [letter pair c0 | c1 << 2][row pair j]
 };
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-template <int NJ> struct CredEntry { typedef u32x4 type; };          // 3 or 4 row pairs: 16-byte entries
+template <int NJ> struct CredEntry { typedef u32x4 type; };          // 3 or 4 row pairs: 16-byte entries; 5..8: two of them
 template <> struct CredEntry<2> { typedef u32x2 type; };
 template <> struct CredEntry<1> { typedef uint32_t type; };
 
@@ -551,10 +551,12 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     constexpr int LET_TILE = BLOCK * W;
     constexpr int NPOS = W + 4 * NJ - 2;               // positions a lane looks up: q = 0 .. W + 4 NJ - 3
     constexpr int NWD = (NPOS + 1 + 3) / 4;            // code dwords holding bytes 0 .. NPOS (the pair at q needs byte q + 1)
-    constexpr int ESH = NJ == 1 ? 2 : (NJ == 2 ? 3 : 4);   // log2 of the entry size in bytes
+    constexpr int ESH = NJ == 1 ? 2 : (NJ == 2 ? 3 : (NJ <= 4 ? 4 : 5));   // log2 of the entry size in bytes
+    constexpr int ZSH = ESH < 4 ? ESH : 4;             // entry offsets travel as bytes (<= 0xF0): 32-byte entries are doubled at use
+    constexpr int TROWS = NJ <= 4 ? 16 : 32;           // rows of the exact letter table (rows m .. are zeros)
     constexpr int NWAVE = BLOCK / 64;
     typedef typename CredEntry<NJ>::type entry_t;
-    __shared__ __align__(16) double tbl[16 * 8];
+    __shared__ __align__(16) double tbl[TROWS * 8];
     __shared__ __align__(16) uint32_t ctab[16 << (ESH - 2)];
     __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
     __shared__ int64_t q_pos[NWAVE][WQ_CAP];
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
 
     CodeStage<LET_TILE> cs;
     cs.fetch(a.codes, first, n_pos);
-    // rows m .. 15 are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
-    for (int i = threadIdx.x; i < 16 * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
+    // rows m .. are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
+    for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
     for (int i = threadIdx.x; i < (16 << (ESH - 2)); i += BLOCK) ctab[i] = ct.d[i >> (ESH - 2)][i & ((1 << (ESH - 2)) - 1)];
     if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
     cs.park(cbuf[0]);
@@ -630,12 +632,12 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         if (lane < cnt) {
             const int64_t p = my_sv[at + lane];
             const int64_t al = p & ~(int64_t)3;
-            uint32_t raw[5];
+            uint32_t raw[NJ + 1];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) raw[k] = load_codes4(a.codes, al + 4 * k, n_pos);
+            for (int k = 0; k < NJ + 1; ++k) raw[k] = load_codes4(a.codes, al + 4 * k, n_pos);
             double sc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NJ; ++k) {
                 const uint32_t cw = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -661,11 +663,11 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         uint32_t w[NWD + 1];
 #pragma unroll
         for (int d = 0; d < NWD + 1; ++d) w[d] = *reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d);   // inside the halo
-        // z[d] byte k = entry offset of the pair at byte 4d+k: (c[4d+k] | c[4d+k+1] << 2) << ESH  (<= 0xF0)
+        // z[d] byte k = entry offset of the pair at byte 4d+k: (c[4d+k] | c[4d+k+1] << 2) << ZSH  (<= 0xF0)
         uint32_t z[NWD];
 #pragma unroll
         for (int d = 0; d < NWD; ++d) {
-            const uint32_t x0 = (w[d] & 0x03030303u) << ESH, x1 = (w[d + 1] & 0x03030303u) << ESH;
+            const uint32_t x0 = (w[d] & 0x03030303u) << ZSH, x1 = (w[d + 1] & 0x03030303u) << ZSH;
             z[d] = x0 | (__builtin_amdgcn_alignbit(x1, x0, 8) << 2);
         }
         // one look-up per position; P[w + 2] in the text above is pk[w + 2] here (w = -2 .. W-1)
@@ -674,14 +676,18 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         for (int i = 0; i < W + 2; ++i) pk[i] = 0u;
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
-            const uint32_t off = (z[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
-            const entry_t e = *reinterpret_cast<const entry_t *>(cbytes + off);
-            uint32_t dj[4] = {0u, 0u, 0u, 0u};
+            const uint32_t off = ((z[q >> 2] >> ((q & 3) * 8)) & 0xFFu) << (ESH - ZSH);
+            uint32_t dj[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             if constexpr (NJ == 1) {
-                dj[0] = e;
-            } else {
+                dj[0] = *reinterpret_cast<const entry_t *>(cbytes + off);
+            } else if constexpr (NJ <= 4) {
+                const entry_t e = *reinterpret_cast<const entry_t *>(cbytes + off);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) dj[j] = e[j];
+            } else {                                   // 5..8 row pairs: a 32-byte entry
+                const u32x4 e0 = *reinterpret_cast<const u32x4 *>(cbytes + off), e1 = *reinterpret_cast<const u32x4 *>(cbytes + off + 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) dj[j] = j < 4 ? e0[j] : e1[j - 4];
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -1237,6 +1243,39 @@ static hipError_t allow_full_lds(const void *kern)
     return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
 }
 
+// integer position-keyed prefilter (k_letters_cred) for a single 4-letter motif of width <= 32 with a finite threshold;
+// false when the motif has +inf / NaN two-letter sums (the fp32 prefilter handles those)
+static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
+{
+    if (!(a.hits && a.pair_table && a.h_pairsum && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
+    constexpr int CRED_TILE = BLOCK * 16;              // k_letters_cred: 16 windows per lane
+    const int npair = (a.m + 1) / 2, nj = (npair + 1) / 2;
+    uint16_t cr[16 * 16];
+    const double slack = build_credits(a.h_pairsum, npair, a.thr_seq, cr);
+    if (!std::isfinite(slack)) return false;
+    CredTable ct;
+    std::memset(&ct, 0, sizeof(ct));
+    for (int i = 0; i < 16; ++i)
+        for (int tr = 0; tr < npair; ++tr) ct.d[i][tr >> 1] |= (uint32_t)cr[tr * 16 + i] << (16 * (tr & 1));
+    ScanArgs b = a;
+    const int64_t ntiles = (a.n_pos + CRED_TILE - 1) / CRED_TILE;
+    b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+    if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
+    const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
+    switch (nj) {
+    case 1: hipLaunchKernelGGL((k_letters_cred<1>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    case 2: hipLaunchKernelGGL((k_letters_cred<2>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    case 3: hipLaunchKernelGGL((k_letters_cred<3>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    case 4: hipLaunchKernelGGL((k_letters_cred<4>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    case 5: hipLaunchKernelGGL((k_letters_cred<5>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    case 6: hipLaunchKernelGGL((k_letters_cred<6>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    case 7: hipLaunchKernelGGL((k_letters_cred<7>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    default: hipLaunchKernelGGL((k_letters_cred<8>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    }
+    *err = hipGetLastError();
+    return true;
+}
+
 template <int NDW>
 static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
@@ -1244,28 +1283,6 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
     // 8 windows per thread (hits: 0.39 vs 0.49 ms on C2 w=12; scores, with the LDS transpose that keeps
     // the stores 1 KiB contiguous: 0.39 vs 0.42 ms on C2 w=8; without the transpose 0.56 ms)
-    if (a.hits && a.pair_table && a.h_pairsum && a.m <= 16 && t.credits && std::isfinite(a.thr_seq) && NDW == 5) {
-        // integer position-keyed prefilter (k_letters_cred): tile = 4096 windows as below
-        const int npair = (a.m + 1) / 2, nj = (npair + 1) / 2;
-        uint16_t cr[8 * 16];
-        const double slack = build_credits(a.h_pairsum, npair, a.thr_seq, cr);
-        if (std::isfinite(slack)) {                   // +inf / NaN two-letter sums: the fp32 prefilter below handles them
-            CredTable ct;
-            std::memset(&ct, 0, sizeof(ct));
-            for (int i = 0; i < 16; ++i)
-                for (int tr = 0; tr < npair; ++tr) ct.d[i][tr >> 1] |= (uint32_t)cr[tr * 16 + i] << (16 * (tr & 1));
-            ScanArgs b = a;
-            const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
-            b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
-            if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
-            const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
-            if (nj == 1) hipLaunchKernelGGL((k_letters_cred<1>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-            else if (nj == 2) hipLaunchKernelGGL((k_letters_cred<2>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-            else if (nj == 3) hipLaunchKernelGGL((k_letters_cred<3>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-            else hipLaunchKernelGGL((k_letters_cred<4>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-            return hipGetLastError();
-        }
-    }
     if (a.hits && a.pair_table) {
         // >= 2048 workgroups when the stream allows, at most 32 tiles per workgroup
         ScanArgs b = a;
@@ -1289,6 +1306,8 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
 
 static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
+    hipError_t e = hipSuccess;
+    if (launch_letters_cred(a, t, stream, &e)) return e;
     if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
     if (a.m <= 32) return launch_letters_ndw<9>(a, t, stream);
     return launch_letters_ndw<17>(a, t, stream);
