@@ -209,6 +209,8 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
     reference's columns, rows in record order then by Start (``columns=True``: possibly as compact columns,
     see table.py)."""
     is_rna = fasta.is_rna_letters(letters)
+    if not hasattr(records, "__len__"):
+        records = list(records)                                 # any iterable of Records
     if not len(records):
         return pd.DataFrame(columns=SEQ_COLUMNS)
     if is_rna:
