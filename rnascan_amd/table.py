@@ -138,7 +138,10 @@ def _descriptor(col, n):
     if isinstance(col, Indexed):
         if len(col) != n:
             raise ValueError("column length mismatch")
-        # only the values some row uses are stringified
+        if isinstance(col.values, (list, tuple)) and len(col.values) <= max(4096, n // 8):
+            off, blob = _blob(col.values)            # a short list (motif ids): every value, the index as it is
+            return (_lib.TSV_INDEXED, col.index, off, blob, 0)
+        # many (or lazily decoded) values: only those some row uses are stringified
         used, inv = np.unique(col.index, return_inverse=True)
         off, blob = _blob([col.values[i] for i in used.tolist()])
         return (_lib.TSV_INDEXED, inv.astype(np.int64), off, blob, 0)
