@@ -67,7 +67,14 @@ class Stream(object):
     def locate(self, pos):
         """stream positions -> (record index, 0-based start within the record)."""
         pos = np.asarray(pos, dtype=np.int64)
-        rec = np.searchsorted(self.offsets, pos, side="right") - 1
+        if pos.size > 4 * self.offsets.size and bool(np.all(pos[1:] >= pos[:-1])):
+            # many sorted positions (hit lists are): count the positions of every record instead of searching per position
+            cuts = np.searchsorted(pos, self.offsets, side="left")
+            rec = np.repeat(np.arange(self.offsets.size, dtype=np.int64), np.diff(np.append(cuts, pos.size)))
+            if rec.size != pos.size:                       # positions before the first record: not a hit list
+                rec = np.searchsorted(self.offsets, pos, side="right") - 1
+        else:
+            rec = np.searchsorted(self.offsets, pos, side="right") - 1
         return rec, pos - self.offsets[rec]
 
     def record_slice(self, r, m):
