@@ -342,6 +342,8 @@ def main(argv=None, engine=None, out=None):
             else:
                 final = struct_results
 
+    if writer[0] is not None:
+        writer[0].close()                        # the last chunk may still be on the writer thread
     if rank == 0 and writer[0] is None:
         # Match_ID 1..n after all filtering / joining (rnascan.py:329-332), then the same bytes as
         # DataFrame.to_csv(sep='\t', index=False) (:559-567), written chunk by chunk

@@ -183,13 +183,19 @@ class TsvWriter(object):
     Indexed | Spans | Windows (a DataFrame's columns work as arrays)."""
 
     MAX_ROWS = 1 << 22                          # rows per native call (~0.5 GB of row buffer at the widest tables)
+    ASYNC_ROWS = 1 << 18                        # chunks of at least this many rows are written out beside the next one's formatting
 
     def __init__(self, out, columns, match_id=True):
         self.out = out
         self.columns = list(columns)
         self.match_id = match_id
         self.rows = 0
-        self._scratch = [None]                   # row buffer reused from chunk to chunk
+        # two row buffers, reused from chunk to chunk: while one is being written out by the writer thread the next
+        # chunk is formatted into the other (a table of 10^7+ rows is bound by exactly these two steps)
+        self._scratch = [[None], [None]]
+        self._busy = [None, None]                # the write still reading each buffer
+        self._turn = 0
+        self._pool = None
         out.write("\t".join([_quote(c) for c in self.columns] + (["Match_ID"] if match_id else [])) + "\n")
 
     def write_chunk(self, data, n=None):
@@ -203,15 +209,53 @@ class TsvWriter(object):
                 self.write_chunk({c: _rows(data[c], a, b) for c in self.columns}, b - a)
             return
         desc = [_descriptor(data[c], n) for c in self.columns]
-        pieces = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1, scratch=self._scratch)
+        k = self._turn
+        self._turn ^= 1
+        if self._busy[k] is not None:
+            self._busy[k].result()               # the write that was reading this buffer (raises what it raised)
+            self._busy[k] = None
+        pieces = _lib.tsv_format(desc, n, self.rows + 1 if self.match_id else -1, scratch=self._scratch[k])
         raw = getattr(self.out, "buffer", None)
         if raw is not None and getattr(self.out, "encoding", "utf-8").lower().replace("-", "") == "utf8":
-            self.out.flush()
-            for piece in pieces:
-                raw.write(piece)                 # a text stream over a byte stream: no decode / re-encode of the rows
+            # a text stream over a byte stream: no decode / re-encode of the rows.  Large chunks go out on the writer
+            # thread (ONE thread: the chunks stay in order) while the next one is formatted
+            if n >= self.ASYNC_ROWS:
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(max_workers=1)
+                    self.out.flush()
+                self._busy[k] = self._pool.submit(self._write_pieces, raw, pieces)
+            else:
+                self.finish()
+                self.out.flush()
+                self._write_pieces(raw, pieces)
         else:
             self.out.write(b"".join(pieces).decode("utf-8"))
         self.rows += n
+
+    @staticmethod
+    def _write_pieces(raw, pieces):
+        for piece in pieces:
+            raw.write(piece)
+
+    def finish(self):
+        """wait for the writer thread (call before anything else writes to the stream, and at the end)"""
+        for k in (self._turn, self._turn ^ 1):   # oldest first
+            if self._busy[k] is not None:
+                self._busy[k].result()
+                self._busy[k] = None
+
+    def close(self):
+        self.finish()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_frame(out, df, match_id=True, chunk=1 << 20):
@@ -220,4 +264,5 @@ def write_frame(out, df, match_id=True, chunk=1 << 20):
     for lo in range(0, len(df), chunk):
         part = df.iloc[lo:lo + chunk]
         w.write_chunk({c: part[c].to_numpy() for c in df.columns}, len(part))
+    w.close()
     return w.rows

@@ -171,12 +171,14 @@ def test_writer_bytes_equal_to_csv(tmp_path):
     path = os.path.join(str(tmp_path), "o.tsv")          # a real text file: rows go to its byte buffer
     with open(path, "w", encoding="utf-8", newline="") as f:
         w = table.TsvWriter(f, list(cols))
+        w.ASYNC_ROWS = 1000                                # the chunks of 1234 go out on the writer thread, the last one does not
         for lo in range(0, n, 1234):
             part = {k: (v if isinstance(v, str) else
                         table.Indexed(v.values, v.index[lo:lo + 1234]) if isinstance(v, table.Indexed) else
                         table.Windows(v.codes, v.pos[lo:lo + 1234], v.m, v.letters) if isinstance(v, table.Windows) else
                         v[lo:lo + 1234]) for k, v in cols.items()}
             w.write_chunk(part)
+        w.close()
     with open(path, "r", encoding="utf-8", newline="") as f:
         assert f.read() == expected
 

@@ -124,7 +124,7 @@ for name, argv in runs:
     path = os.path.join(d, "out.tsv")
     with open(path, "w", encoding="utf-8", newline="") as out:
         prof = None
-        if os.environ.get("CLI_E2E_PROFILE") and (name.startswith("big") or name.startswith("library")):
+        if os.environ.get("CLI_E2E_PROFILE") and (name.startswith("big") or name.startswith("library") or "-inf" in name):
             import cProfile, pstats
             prof = cProfile.Profile()
             prof.enable()
