@@ -384,3 +384,25 @@ def test_staged_upload_of_a_mapped_store_equals_the_runtime_copy(ctx, tmp_path, 
     ctx.stage(codes, prof)
     assert ctx._upload_mode == 0
     motif.close()
+
+
+def test_mapped_store_of_300_mb_takes_the_staged_upload_by_itself(ctx, tmp_path, monkeypatch):
+    """no environment override: a memory-mapped profile of more than 256 MB selects PFMSCAN_UPLOAD_STAGED in the Python
+    layer and goes up through the pinned pieces; the structure scores equal those of the in-memory copy"""
+    from test_gpu_parity import rand_struct_pssm
+    monkeypatch.delenv("PFMSCAN_UPLOAD", raising=False)
+    rng = np.random.default_rng(8)
+    n_pos = 10_500_003                                       # 294 MB of float32 rows, a ragged last piece
+    prof = rng.random((n_pos, 7), dtype=np.float32)
+    path = str(tmp_path / "big.f32")
+    prof.tofile(path)
+    mapped = np.memmap(path, dtype=np.float32, mode="r", shape=(n_pos, 7))
+    motif = ctx.motif(None, rand_struct_pssm(rng, 12, inf_frac=0.0))
+    _, want = ctx.scan_host(motif, None, prof, want_seq=False)
+    assert ctx._upload_mode == 0
+    _, got = ctx.scan_host(motif, None, mapped, want_seq=False)
+    assert ctx._upload_mode == 1
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    ctx.stage(None, prof)                                    # and back to the runtime's copy for ordinary memory
+    assert ctx._upload_mode == 0
+    motif.close()
