@@ -16,7 +16,10 @@
  *     memory and never returns memory the caller must free.  Device scratch is
  *     owned by the ctx, PSSM tables by the motif object.
  *   - a ctx is bound to one device and may be used by one host thread at a
- *     time; use one ctx per device / per thread.  No global mutable state.
+ *     time; use one ctx per device / per thread.  No global mutable state: the
+ *     host-only entry points (FASTA / profile text / TSV, no ctx) may be called
+ *     from any number of threads, their message (pfmscan_last_error(NULL)) is
+ *     thread-local.
  *   - positions are 0-based at this level; rnascan's 1-based inclusive
  *     Start/End (rnascan.py:264-271, :311) are made in the table layer.
  *
