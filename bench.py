@@ -88,9 +88,54 @@ def make_stream(torch, dev, records, length, seed, foreign=0.0, zero_snap=False)
     return codes.view(-1), profile, n_pos
 
 
+def dry_run(args, world):
+    """PFMSCAN_BENCH_DRYRUN=1: the multi-rank plumbing WITHOUT the hot path -- rank environment, process group (gloo),
+    barrier, MAX over ranks, per-rank gather, rank 0's line -- for the launcher test on a machine without a GPU.  No
+    score is computed and no throughput is reported (value = null, "dry_run": true); a "step" is a 1 ms host sleep."""
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("PFMSCAN_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                       # the launcher test's failing rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = elapsed / args.steps * 1e3
+    rank_ms = [kernel_ms]
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        box = [None] * world
+        dist.all_gather_object(box, kernel_ms)
+        rank_ms = box
+    result = None
+    if rank == 0:
+        result = {"metric": "DRY RUN of the multi-rank launcher (no GPU work, no score computed)", "value": None, "unit": "windows/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none", "dry_run": True,
+                  "config": {"workload": "none (PFMSCAN_BENCH_DRYRUN=1)"}, "per_rank": {"kernel_ms": rank_ms}}
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node to run on [1].  Under a launcher (WORLD_SIZE set, e.g. torch.distributed.run "
+                         "--nproc-per-node N) it must equal WORLD_SIZE; without one, N > 1 makes this process the parent of N "
+                         "ranks (rnascan_amd/launch.py: it never touches a GPU itself) and relays rank 0's JSON line")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--settle", type=int, default=15,
@@ -137,6 +182,21 @@ def main():
         args.minscore_seq = args.minscore_struct = args.minscore
     if args.from_host and args.mode == "scores":
         args.mode = "hits"
+    # ---- N GPUs from one command: the parent starts N ranks BEFORE anything here touches a GPU (no torch.cuda call, no
+    # _lib.Context), waits, and prints what rank 0 printed; a failing rank makes it exit non-zero
+    from rnascan_amd import launch
+    world, must_spawn = launch.resolve_world(args.gpus)
+    if must_spawn:
+        rc, text = launch.spawn_ranks(world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], capture_rank0=True)
+        for ln in (text or "").splitlines():     # stdout = the result line only; anything else rank 0 printed goes to stderr
+            (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+        sys.stdout.flush()
+        if rc == 0 and not any(ln.startswith("{") and '"n_gpus": %d' % world in ln for ln in (text or "").splitlines()):
+            sys.stderr.write("bench.py: rank 0 printed no result line for %d GPUs\n" % world)
+            rc = 1
+        sys.exit(rc)
+    if os.environ.get("PFMSCAN_BENCH_DRYRUN") == "1":
+        return dry_run(args, world)
     # the cpu_baseline leg uses every logical CPU this process may run on (north_star: "all host cores").  libgomp reads
     # OMP_NUM_THREADS when it is LOADED (torch loads it), and its own default stops at 128 of this box's 256 CPUs.
     os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()))
@@ -146,7 +206,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.records is None:
         args.records = 125000 if world == 8 else 100000
     if not torch.cuda.is_available():

@@ -20,6 +20,9 @@ from . import fasta, pack, pssm as pssm_mod, scanner, shard, store, table
 from . import __version__
 
 
+RANK_COMMAND = [sys.executable, "-m", "rnascan_amd"]      # what --gpus N starts once per rank (followed by the arguments)
+
+
 def getoptions(argv=None):
     desc = "Scan sequence for motif binding sites. Results sent to STDOUT."
     parser = argparse.ArgumentParser(prog="rnascan", description=desc)
@@ -54,6 +57,10 @@ def getoptions(argv=None):
     gpu = parser.add_argument_group("MI355X options (not in the reference)")
     gpu.add_argument("--device", type=int, default=int(os.environ.get("RNASCAN_DEVICE", "0")),
                      help="HIP device index [%(default)s]")
+    gpu.add_argument("--gpus", type=int, default=None,
+                     help=("scan on this many GPUs of the node, one process per GPU, records sharded over them (the analogue "
+                           "of the reference's -c: its Pool fan-out).  This process then only starts the ranks and waits; "
+                           "rank 0 prints the table [1]"))
     gpu.add_argument("--pairing", choices=["aligned", "positional"], default="aligned",
                      help=("averaged-structure columns vs structure PFM: 'aligned' pairs by letter, 'positional' "
                            "reproduces the reference on Python 3 (file order BEHLMRT against EHTBLRM) [%(default)s]"))
@@ -183,14 +190,36 @@ def _init_distributed(args):
         import torch
         torch.cuda.set_device(args.device)
     if not dist.is_initialized():
-        dist.init_process_group(backend)
+        # stdout carries the hit table and nothing else: gloo announces its connections on fd 1 ("[Gloo] Rank 0 is
+        # connected to ..."), so the rendezvous (and the first collective, which completes the mesh) runs with fd 1
+        # pointing at stderr
+        sys.stdout.flush()
+        keep = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group(backend)
+            dist.barrier()
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
     return rank, world, dist
 
 
 def main(argv=None, engine=None, out=None):
     tic = time.time()
-    out = out or sys.stdout
     args = getoptions(argv)
+    if engine is None and out is None and not args.testseq:
+        # --gpus N without an outer launcher: become the parent of N ranks (rnascan.py:388-395 starts Pool(args.cores)
+        # at this point).  The parent touches no GPU; rank 0 inherits stdout, so the table goes where it always went.
+        from . import launch
+        world, must_spawn = launch.resolve_world(args.gpus)
+        if must_spawn:
+            pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            path = os.pathsep.join([pkg_parent] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p])
+            rc, _ = launch.spawn_ranks(world, list(RANK_COMMAND) + list(sys.argv[1:] if argv is None else argv),
+                                       extra_env={"PYTHONPATH": path})
+            return rc
+    out = out or sys.stdout
     seq_type = _guess_seq_type(args)
     testseq_stack = args.testseq.split(",")[::-1] if args.testseq else None
     own_engine = False
