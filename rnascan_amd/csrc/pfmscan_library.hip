@@ -59,76 +59,72 @@ __device__ __forceinline__ uint32_t lib_codes4(const uint8_t *__restrict__ codes
 }
 
 // structure score of the window at stream position p for pass-local motif mo: rows from global memory as
-// element-aligned 4-vectors (7 loads per 4 rows, see struct_score_at in pfmscan_kernels.hip), PSSM cells from the
-// transposed LDS copy pssm[((j*4 + c/2)*NMP + mo)*2 + (c&1)] -- rows padded to 8 columns, two columns per 16 bytes, so
-// a row is four ds_read_b128 (as 8-byte reads hipcc pairs them into ds_read2_b64: twice the LDS cycles per value).
-// Neighbouring motifs are 16 bytes apart: the distinct motifs of a wave spread over the banks; NMP is a
-// compile-time constant, so the cell offsets are immediates.
+// element-aligned 16-byte vectors -- a BLOCK is 7 of them = 4 float rows or 2 double rows (see struct_score_at in
+// pfmscan_kernels.hip) -- PSSM cells from the transposed LDS copy pssm[((j*4 + c/2)*NMP + mo)*2 + (c&1)]: rows padded to
+// 8 columns, two columns per 16 bytes, so a row is four ds_read_b128 (as 8-byte reads hipcc pairs them into
+// ds_read2_b64: twice the LDS cycles per value).  Neighbouring motifs are 16 bytes apart: the distinct motifs of a wave
+// spread over the banks; NMP is a compile-time constant, so the cell offsets are immediates.
+// Two blocks (2 x 28 VGPRs, either precision) are in flight and the values are used from the vectors they arrived in:
+// the double variant used to hold two 4-row blocks = 112 VGPRs + an unpacked copy and spilled 144 bytes per lane.
 template <typename PROF_T, int NMP>
 __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t p, int m, const double *pssm_lds, int mo)
 {
-    typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+    constexpr int RB = 16 / (int)sizeof(PROF_T);       // rows per block = elements per vector: 4 (float) or 2 (double)
+    typedef PROF_T vec_t __attribute__((ext_vector_type(RB), aligned(sizeof(PROF_T))));
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(profile) + p * 7;
     const f64x2 *P = reinterpret_cast<const f64x2 *>(pssm_lds) + mo;
     double score = 0.0;
-    // rows [base, base + 4) of the window as 7 four-vectors; the last block of a width that is no multiple of 4 starts
-    // at m - 4 and skips the rows it shares with the block before
-    auto block_base = [&](int j0) { return j0 < m - 4 ? j0 : m - 4; };
-    auto fetch = [&](int j0, v4_t (&q)[7]) {
+    // rows [base, base + RB) of the window as 7 vectors; the last block of a width that is no multiple of RB starts
+    // at m - RB and skips the rows it shares with the block before
+    auto block_base = [&](int j0) { return j0 < m - RB ? j0 : m - RB; };
+    auto fetch = [&](int j0, vec_t (&q)[7]) {
         const PROF_T *r = prof + block_base(j0) * 7;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) q[k] = *reinterpret_cast<const v4_t *>(r + 4 * k);
+        for (int k = 0; k < 7; ++k) q[k] = *reinterpret_cast<const vec_t *>(r + RB * k);
     };
-    auto rows = [&](int j0, const PROF_T (&val)[28]) {
-        const int base = m >= 4 ? block_base(j0) : j0;
+    auto row_dot = [&](int j, double v0, double v1, double v2, double v3, double v4, double v5, double v6) {
+        const f64x2 *Pj = P + (size_t)j * 4 * NMP;
+        const f64x2 p01 = Pj[0], p23 = Pj[NMP], p45 = Pj[2 * NMP], p67 = Pj[3 * NMP];
+        double d = v0 * p01.x;
+        d = fma(v1, p01.y, d);
+        d = fma(v2, p23.x, d);
+        d = fma(v3, p23.y, d);
+        d = fma(v4, p45.x, d);
+        d = fma(v5, p45.y, d);
+        d = fma(v6, p67.x, d);
+        score += lib_nan_to_num(d);
+    };
+    // element e (0 .. 7 RB - 1) of a block = row e / 7, column e % 7; it sits in q[e / RB][e % RB]
+    auto rows = [&](int j0, const vec_t (&q)[7]) {
+        const int base = block_base(j0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RB; ++u) {
             const int j = base + u;
             if (j >= j0 && j < m) {
-                const f64x2 *Pj = P + (size_t)j * 4 * NMP;
-                const f64x2 p01 = Pj[0], p23 = Pj[NMP], p45 = Pj[2 * NMP], p67 = Pj[3 * NMP];
-                double d = (double)val[u * 7] * p01.x;
-                d = fma((double)val[u * 7 + 1], p01.y, d);
-                d = fma((double)val[u * 7 + 2], p23.x, d);
-                d = fma((double)val[u * 7 + 3], p23.y, d);
-                d = fma((double)val[u * 7 + 4], p45.x, d);
-                d = fma((double)val[u * 7 + 5], p45.y, d);
-                d = fma((double)val[u * 7 + 6], p67.x, d);
-                score += lib_nan_to_num(d);
+#define LIB_EL(c) ((double)q[(u * 7 + (c)) / RB][(u * 7 + (c)) % RB])
+                row_dot(j, LIB_EL(0), LIB_EL(1), LIB_EL(2), LIB_EL(3), LIB_EL(4), LIB_EL(5), LIB_EL(6));
+#undef LIB_EL
             }
         }
     };
-    auto unpack = [&](const v4_t (&q)[7], PROF_T (&val)[28]) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            val[4 * k] = q[k][0];
-            val[4 * k + 1] = q[k][1];
-            val[4 * k + 2] = q[k][2];
-            val[4 * k + 3] = q[k][3];
-        }
-    };
-    if (m < 4) {                                       // narrower than one block: element loads
-        PROF_T val[28];
-#pragma unroll
-        for (int e = 0; e < 28; ++e) val[e] = e < m * 7 ? prof[e] : (PROF_T)0;
-        rows(0, val);
+    if (m < RB) {                                      // narrower than one block: element loads
+        for (int j = 0; j < m; ++j)
+            row_dot(j, (double)prof[j * 7], (double)prof[j * 7 + 1], (double)prof[j * 7 + 2], (double)prof[j * 7 + 3],
+                    (double)prof[j * 7 + 4], (double)prof[j * 7 + 5], (double)prof[j * 7 + 6]);
         return score;
     }
-    // two blocks in flight: the loads of block j0 + 4 are issued before block j0 is scored, so a batch waits for the
+    // two blocks in flight: the loads of block j0 + RB are issued before block j0 is scored, so a batch waits for the
     // memory once, not once per block (the 16 waves of a CU are not enough to hide three round trips per batch)
-    v4_t qa[7], qb[7];
-    PROF_T val[28];
+    vec_t qa[7], qb[7];
     fetch(0, qa);
-    for (int j0 = 0; j0 < m; j0 += 8) {
-        const bool more1 = j0 + 4 < m, more2 = j0 + 8 < m;
-        if (more1) fetch(j0 + 4, qb);
-        unpack(qa, val);
-        rows(j0, val);
+    for (int j0 = 0; j0 < m; j0 += 2 * RB) {
+        const bool more1 = j0 + RB < m, more2 = j0 + 2 * RB < m;
+        if (more1) fetch(j0 + RB, qb);
+        rows(j0, qa);
         if (more1) {
-            if (more2) fetch(j0 + 8, qa);
-            unpack(qb, val);
-            rows(j0 + 4, val);
+            if (more2) fetch(j0 + 2 * RB, qa);
+            rows(j0 + RB, qb);
         }
     }
     return score;
@@ -140,15 +136,18 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
 template <int K, int NP>
 __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const int off)
 {
+    // look-ups in flight before the first add: 8 rows (all of them for PFMs up to width 16); the wider buckets, whose 16 or
+    // 32 row addresses already fill the register budget of a 16-wave workgroup, take 4 at a time (8 spilled 20-36 bytes)
+    constexpr int CH = NP > 8 ? 4 : 8;
     u32x4 acc = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t0 = 0; t0 < K; t0 += 8) {
-        u32x4 r[8];
+    for (int t0 = 0; t0 < K; t0 += CH) {
+        u32x4 r[CH];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < CH; ++i)
             if (t0 + i < K) r[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(rowp[t0 + i] + off);
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
+        for (int i = 0; i < CH; i += 2) {
             if (t0 + i + 1 < K) {
                 acc.x = acc.x + r[i].x + r[i + 1].x;
                 acc.y = acc.y + r[i].y + r[i + 1].y;
@@ -161,6 +160,7 @@ __device__ __forceinline__ u32x4 lib_credits(const lds_cptr (&rowp)[NP], const i
                 acc.w += r[i].w;
             }
         }
+        if (NP > 8 && t0 + CH < K) __builtin_amdgcn_sched_barrier(0);      // or hipcc hoists every look-up to the front again
     }
     return acc;
 }
@@ -444,8 +444,11 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             for (int k = 0; k < NP / 2; ++k) {
                 const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(lane & 3));
                 // letters 4k .. 4k+3 of the window; only the first m count
+                // (a width bucket starts above the previous one: m > NP for NP > 8, so its first NP / 4 dwords always count
+                // in full -- constants instead of eight scalar masks kept live across the whole chunk loop)
                 const int nb = m - 4 * k;
-                const uint32_t vm = nb >= 4 ? 0x04040404u : (nb > 0 ? (0x04040404u & ((1u << (8 * nb)) - 1u)) : 0u);
+                const uint32_t vm = (NP > 8 && 4 * k + 4 <= NP) ? 0x04040404u
+                                    : (nb >= 4 ? 0x04040404u : (nb > 0 ? (0x04040404u & ((1u << (8 * nb)) - 1u)) : 0u));
                 badbits |= w & vm;
                 const uint32_t x = w & 0x03030303u;
                 const uint32_t y = x | (x >> 6);             // pair (b0,b1) in bits 0-3, pair (b2,b3) in bits 16-19
