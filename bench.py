@@ -149,11 +149,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-structured", action="store_true",
                     help="skip the reference-structured Python baseline (B-ref of BASELINE.md section 3)")
-    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "c5s"], default="c3",
                     help="c3: seq+struct w=12 (the headline metric); c2: sequence-only PFM (BASELINE configs[1], use --width 8); "
                          "c5: a library of --motifs seq+struct PFM pairs over the same resident records, every motif in ONE "
                          "pass of the library kernel, thresholded hits (BASELINE configs[4]); value is then window x motif "
-                         "pairs per second")
+                         "pairs per second; c5s: the STRUCTURE-ONLY library of --motifs PFMs over the resident profile (k_profile_lib: "
+                         "the profile is read once, bound by the fp64 vector rate)")
     ap.add_argument("--motifs", type=int, default=256, help="PFM pairs of --workload c5")
     ap.add_argument("--variant", choices=["finite", "inf"], default="finite",
                     help="finite: pseudocount 0.01 PSSMs (headline); inf: pseudocount 0 PSSMs with -inf cells, profile with "
@@ -230,14 +231,15 @@ def main():
     ctx = _lib.Context(local_rank)
     table, spssm = make_pssms(args.width, args.variant)
     seq_only = args.workload == "c2"
-    is_lib = args.workload == "c5"
+    struct_lib = args.workload == "c5s"
+    is_lib = args.workload in ("c5", "c5s")
     motif = ctx.motif(table, None if seq_only else spssm)
     library = None
     if is_lib:
         args.mode = "library"
         tabs = [make_pssms(args.width, args.variant, seed=1000 + k) for k in range(args.motifs)]      # seeds 1000 + k
         lib_T, lib_P = np.stack([t for t, _ in tabs]), np.stack([p for _, p in tabs])
-        library = ctx.library(lib_T, lib_P)
+        library = ctx.library(None if struct_lib else lib_T, lib_P)
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank,
                                         foreign=0.001 if args.variant == "inf" else 0.0,
                                         zero_snap=args.variant == "inf")
@@ -262,6 +264,24 @@ def main():
     # given, is the quantile that makes the COMBINED hit rate --hit-rate ("threshold chosen for ~1e-4"), so
     # that hit emission, the sharded counters and (library) the structure verification all carry real load
     thr_seq, thr_struct, thr_note = args.minscore_seq, args.minscore_struct, "given"
+    rate_seq = None
+    if struct_lib and thr_struct is None:
+        # structure-only library: the (1 - hit rate) quantile of the structure scores, pooled over up to 8 motifs
+        probe = [tabs[k] for k in range(0, len(tabs), max(1, len(tabs) // 8))][:8]
+        qs = []
+        for tp in probe:
+            m0 = ctx.motif(None, tp[1])
+            ctx.scan_dev(m0, None, profile.data_ptr(), ptype, n_pos, None, out_st.data_ptr(), stream)
+            torch.cuda.synchronize()
+            sel = out_st[torch.isfinite(out_st)]
+            k_top = max(2, int(round(args.hit_rate * sel.numel())))
+            top = torch.topk(sel, k_top).values              # sorted descending
+            qs.append(0.5 * (float(top[-1]) + float(top[-2])))       # between two scores, never ON one
+            m0.close()
+            del sel, top
+        thr_struct = float(np.mean(qs))
+        thr_note = "auto: mean over %d motifs of the (1 - %g) quantile of their structure scores" % (len(probe), args.hit_rate)
+        out_st.zero_()
     if args.mode != "scores" and not seq_only and thr_struct is None:
         # pooled over up to 8 motifs of the library (their score distributions differ), or the one motif
         probe = [tabs[k] for k in range(0, len(tabs), max(1, len(tabs) // 8))][:8] if is_lib else [None]
@@ -312,9 +332,9 @@ def main():
             host_hits[0] = len(pos)
             return
         if is_lib:
-            ctx.library_hits_dev(library, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, thr_seq, thr_struct, cap,
-                                 hit_pos.data_ptr(), hit_motif.data_ptr(), hit_seq.data_ptr(), hit_st.data_ptr(),
-                                 hit_count.data_ptr(), stream)
+            ctx.library_hits_dev(library, None if struct_lib else codes.data_ptr(), profile.data_ptr(), ptype, n_pos,
+                                 None if struct_lib else thr_seq, thr_struct, cap, hit_pos.data_ptr(), hit_motif.data_ptr(),
+                                 None if struct_lib else hit_seq.data_ptr(), hit_st.data_ptr(), hit_count.data_ptr(), stream)
         elif args.mode in ("hits", "hits2"):
             hit_count.zero_()
             (ctx.hits_dev if args.mode == "hits" else ctx.hits_adaptive_dev)(
@@ -416,7 +436,11 @@ def main():
             except Exception:
                 traffic = None
         shard = "C4: 1M" if (world == 8 and args.records == 125000) else "%d x %d" % (world, args.records)
-        if is_lib:
+        if struct_lib:
+            wl = ("C5-struct: library of %d structure PFMs (width %d) x %d synthetic records x %d nt per GPU, resident %s profile, "
+                  "every motif in ONE pass over the profile (k_profile_lib: tile rows staged in LDS as fp64 once, PSSM rows through "
+                  "the scalar cache), thresholded hits per motif" % (n_motifs, args.width, args.records, args.length, args.profile_dtype))
+        elif is_lib:
             wl = ("C5: library of %d seq+struct PFM pairs (width %d) x %d synthetic records x %d nt per GPU, resident stream, "
                   "every motif in one pass (k_library: integer two-letter prefilter in LDS, exact re-score + structure "
                   "verification of the survivors), thresholded hits per motif" % (n_motifs, args.width, args.records, args.length))
@@ -428,7 +452,7 @@ def main():
                                           args.length, args.width, args.profile_dtype,
                                           "all-scores (f32 seq + f64 struct per window)" if args.mode == "scores" else "thresholded hits"))
         result = {
-            "metric": ("scored window x motif pairs/sec (%d-PFM library, seq+struct, w=%d)" % (n_motifs, args.width)) if is_lib
+            "metric": ("scored window x motif pairs/sec (%d-PFM library, %s, w=%d)" % (n_motifs, "struct-only" if struct_lib else "seq+struct", args.width)) if is_lib
                       else "scored windows/sec (%s, w=%d)" % ("seq-only" if seq_only else "seq+struct", args.width),
             "value": total_windows / elapsed,
             "unit": "window-motif pairs/s" if is_lib else "windows/s",
@@ -479,7 +503,23 @@ def main():
             # candidate-then-verify reads 1 B per position plus m rows per candidate: the fused-pass byte
             # count does not describe it, so no roofline figure is given for this mode
             result["roofline"] = None
-        if is_lib:
+        if struct_lib:
+            # bound by the fp64 vector rate: 7 m FMAs per window and motif; v_fma_f64 measured at 36.5 T lane-ops/s = 73 TFLOP/s
+            # (tools/fp64_peak.hip, profiles/r1/fp64_peak.txt; the datasheet's 78.6 TFLOP/s is the same rate at 2.4 GHz)
+            flops = float(windows) * n_motifs * args.width * 7 * 2
+            tf = flops / (kernel_ms * 1e-3) / 1e12
+            result["roofline"] = {
+                "bound": "fp64", "achieved": tf, "peak": 73.0, "unit": "TFLOP/s", "frac": tf / 73.0, "traffic": None,
+                "kernel": "k_profile_lib<%s>" % ("float" if ptype == _lib.PROFILE_F32 else "double"),
+                "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
+                "kernel_ms_max": float(step_ms.max()), "algorithmic_flops_per_launch": flops,
+                "algorithmic_unit": "fp64 FLOP: windows x motifs x 7 w FMAs x 2",
+                "peak_source": "measured v_fma_f64 rate (profiles/r1/fp64_peak.txt); datasheet vector fp64 78.6 TFLOP/s",
+                "frac_of_datasheet_78_6": tf / 78.6,
+                "hbm_frac": (args.records * (args.length + 1) * (28 if ptype == _lib.PROFILE_F32 else 56) + (n_hits or 0) * 20)
+                            / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
+        elif is_lib:
             # The library pass is bound by LDS look-ups, not by HBM: every window x motif needs ceil(w/2) two-byte
             # credits from the LDS tables (ds_read_b128, 256 B/clk/CU).  Beside it: the HBM fraction (codes once per
             # pass + the structure rows of the candidates + hits) and the fp64 work of the verification.

@@ -222,7 +222,14 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,
  * join (:422-423) for the pair (sequence motif k, structure motif k).  Scores are the same numbers the
  * single-motif entry points give (float32 of the sequential fp64 sum; fp64 per-row nan_to_num sum).
  * thr_seq / thr_struct are HOST arrays of n doubles; thr_seq must be > -inf (at -inf every window is a hit:
- * use the all-scores entry points). */
+ * use the all-scores entry points).
+ *
+ * STRUCTURE-ONLY libraries: letter_tables == NULL with struct_pssms given (`rnascan -q library avgdir/`; the reference
+ * would call scan_averaged_structure, rnascan.py:293-315, once per motif and re-read every profile each time).  Every
+ * motif is scored in ONE pass over the profile (k_profile_lib): the tile's rows are staged in LDS once, the motifs'
+ * PSSM rows stream through the scalar cache, any library size is one pass.  Hit of motif k at window p:
+ * struct_k(p) > thr_struct[k] (rnascan.py:310); thr_seq and the codes are ignored (may be NULL), hit_seq comes back NaN.
+ * No codes means no separators: the caller drops windows that run over a record end, as for a structure-only motif. */
 typedef struct pfmscan_library pfmscan_library;
 int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables,
                            const double *struct_pssms, int n_motifs, int m,

@@ -521,10 +521,10 @@ class Context(object):
                 continue
             self._check(rc, k.value)
             k = int(k.value)
-            return pos[:k].copy(), mo[:k].copy(), sq[:k].copy(), (st[:k].copy() if lib.has_struct else None)
+            return pos[:k].copy(), mo[:k].copy(), (sq[:k].copy() if lib.has_letters else None), (st[:k].copy() if lib.has_struct else None)
 
     def library_hits_host(self, lib, codes, profile=None, thr_seq=None, thr_struct=None, capacity=None):
-        self.stage(codes, profile if lib.has_struct else None)
+        self.stage(codes if lib.has_letters else None, profile if lib.has_struct else None)
         return self.library_hits_staged(lib, thr_seq, thr_struct, capacity)
 
     def library_hits_dev(self, lib, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity,
@@ -605,28 +605,35 @@ class Motif(object):
 
 class Library(object):
     """n motifs of one width resident on the device for one-pass scans:
-    letter_tables [n][m][8] (4-letter alphabet), struct_pssms [n][m][7] or None."""
+    letter_tables [n][m][8] (4-letter alphabet), struct_pssms [n][m][7] or None.
+    letter_tables None + struct_pssms: a STRUCTURE-ONLY library (k_profile_lib: every motif in one pass over the profile)."""
 
     def __init__(self, ctx, letter_tables, struct_pssms=None):
         self._ctx = ctx
         self._L = ctx._L
-        lt = np.ascontiguousarray(letter_tables, dtype=np.float64)
-        if lt.ndim != 3 or lt.shape[2] != NCODE:
+        lt = None if letter_tables is None else np.ascontiguousarray(letter_tables, dtype=np.float64)
+        if lt is not None and (lt.ndim != 3 or lt.shape[2] != NCODE):
             raise ValueError("letter_tables must be [n][m][8]")
         sp = None
         if struct_pssms is not None:
             sp = np.ascontiguousarray(struct_pssms, dtype=np.float64)
-            if sp.shape != (lt.shape[0], lt.shape[1], NSTRUCT):
+            if sp.ndim != 3 or sp.shape[2] != NSTRUCT or (lt is not None and sp.shape[:2] != lt.shape[:2]):
                 raise ValueError("struct_pssms must be [n][m][7] with the letter tables' n and m")
-        self.n, self.m = int(lt.shape[0]), int(lt.shape[1])
+        if lt is None and sp is None:
+            raise ValueError("library needs letter tables and/or structure PSSMs")
+        shape = (lt if lt is not None else sp).shape
+        self.n, self.m = int(shape[0]), int(shape[1])
+        self.has_letters = lt is not None
         self.has_struct = sp is not None
         h = ctypes.c_void_p()
         ctx._check(self._L.pfmscan_library_create(ctx._h, _ptr(lt), _ptr(sp), self.n, self.m, ctypes.byref(h)))
         self._h = h
 
     def thresholds(self, thr_seq, thr_struct=None):
-        """scalars or per-motif arrays -> float64 [n] arrays (None for the structure side of a sequence-only library)"""
-        ts = np.ascontiguousarray(np.broadcast_to(np.asarray(thr_seq, dtype=np.float64), (self.n,)))
+        """scalars or per-motif arrays -> float64 [n] arrays (None for a side the library does not have)"""
+        ts = None
+        if self.has_letters:
+            ts = np.ascontiguousarray(np.broadcast_to(np.asarray(thr_seq, dtype=np.float64), (self.n,)))
         tt = None
         if self.has_struct:
             tt = np.ascontiguousarray(np.broadcast_to(np.asarray(-np.inf if thr_struct is None else thr_struct,

@@ -137,6 +137,26 @@ int lib_np_bucket(int m);
 int lib_pick_ng(int np_bucket, int want_groups, int max_groups);   // supported group count of a pass (0: none fits)
 hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream);
 
+// ---- structure-only PFM library (pfmscan_proflib.hip): every motif in one pass over the profile ---------------------
+struct ProfLibArgs {
+    const void *profile;                  // [n_pos][7] float or double
+    int profile_dtype;
+    int64_t n_pos;
+    const double *pssm;                   // [n_motifs][m][7] fp64, row-major as handed to pfmscan_library_create
+    const double *thr;                    // [n_motifs] structure thresholds (hit <=> score > thr, rnascan.py:310)
+    const int32_t *finite;                // [n_motifs] 1 = every cell of the motif's PSSM is finite
+    int n_motifs, m, motif_base;
+    // hits: hit_shards regions of shard_cap slots, counters HIT_COUNTER_STRIDE words apart (workgroup b -> shard b & (shards-1))
+    int64_t shard_cap;
+    int hit_shards;
+    int64_t *hit_pos;
+    int32_t *hit_motif;
+    double *hit_struct;
+    unsigned long long *hit_count;
+};
+hipError_t launch_profile_library(const ProfLibArgs &a, hipStream_t stream);
+int64_t profile_library_tile();           // stream positions per workgroup (workgroup b appends to shard b & (shards - 1))
+
 hipError_t sort_temp_bytes(int64_t total, int key_bits, size_t *bytes);
 hipError_t launch_gather_sorted(const GatherArgs &g, hipStream_t stream);
 

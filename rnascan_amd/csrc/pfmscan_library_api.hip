@@ -18,6 +18,7 @@
 // is 32768 everywhere, every window goes to the exact pass.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -106,6 +107,9 @@ struct pfmscan_library {
     pfmscan_ctx *ctx = nullptr;
     int n = 0, m = 0, npair = 0, np_bucket = 8;
     bool has_struct = false;
+    bool has_letters = true;           // false: structure-only library (k_profile_lib, pfmscan_proflib.hip): one pass, no letter tables
+    double *d_pssm_rows = nullptr;     // structure-only: [n][m][7] fp64 as handed in
+    int32_t *d_finite = nullptr;       // structure-only: [n] 1 = every cell of the motif's PSSM is finite
     std::vector<double> pairsum;       // [n][npair][16] exact two-letter sums, index c0 | c1 << 2
     std::vector<LibPass> passes;
     uint16_t *d_pairs = nullptr;
@@ -124,11 +128,40 @@ extern "C" {
 int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const double *struct_pssms, int n_motifs, int m,
                            pfmscan_library **out)
 {
-    if (!ctx || !out || !letter_tables) return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_create: NULL argument");
+    if (!ctx || !out || (!letter_tables && !struct_pssms)) return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_create: NULL argument");
     *out = nullptr;
     if (n_motifs < 1 || n_motifs > 65535) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "library size outside 1..65535");
     if (m < 1 || m > PFMSCAN_MAX_M)
         return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "PFM width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    if (!letter_tables) {
+        // structure-only library: the PSSMs stay in global memory (k_profile_lib reads them through the scalar cache)
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        pfmscan_library *lib = new (std::nothrow) pfmscan_library();
+        if (!lib) return lib_fail(ctx, PFMSCAN_E_OOM, "out of host memory");
+        lib->ctx = ctx;
+        lib->n = n_motifs;
+        lib->m = m;
+        lib->has_struct = true;
+        lib->has_letters = false;
+        std::vector<int32_t> fin((size_t)n_motifs, 1);
+        for (int k = 0; k < n_motifs; ++k)
+            for (int i = 0; i < m * 7; ++i)
+                if (!std::isfinite(struct_pssms[(size_t)k * m * 7 + i])) fin[(size_t)k] = 0;
+        if (std::getenv("PFMSCAN_FORCE_GENERIC")) std::fill(fin.begin(), fin.end(), 0);
+        const size_t cells = (size_t)n_motifs * m * 7;
+        hipError_t e = hipMalloc((void **)&lib->d_pssm_rows, cells * 8);
+        if (e == hipSuccess) e = hipMemcpy(lib->d_pssm_rows, struct_pssms, cells * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&lib->d_finite, (size_t)n_motifs * 4);
+        if (e == hipSuccess) e = hipMemcpy(lib->d_finite, fin.data(), (size_t)n_motifs * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&lib->d_thr, (size_t)n_motifs * 8);
+        lib->thr_elems = (size_t)n_motifs;
+        if (e != hipSuccess) {
+            pfmscan_library_destroy(lib);
+            return fail_hip(ctx, e, "uploading the library tables");
+        }
+        *out = lib;
+        return PFMSCAN_OK;
+    }
     for (int64_t i = 0; i < (int64_t)n_motifs * m; ++i)
         for (int c = 4; c < 8; ++c)
             if (!std::isnan(letter_tables[i * 8 + c]))
@@ -213,6 +246,8 @@ void pfmscan_library_destroy(pfmscan_library *lib)
     if (lib->d_letters) (void)hipFree(lib->d_letters);
     if (lib->d_pssm) (void)hipFree(lib->d_pssm);
     if (lib->d_thr) (void)hipFree(lib->d_thr);
+    if (lib->d_pssm_rows) (void)hipFree(lib->d_pssm_rows);
+    if (lib->d_finite) (void)hipFree(lib->d_finite);
     delete lib;
 }
 
@@ -234,8 +269,8 @@ int pfmscan_library_info(const pfmscan_library *lib, int *n_motifs, int *m, int 
     if (!lib) return PFMSCAN_E_BADARG;
     if (n_motifs) *n_motifs = lib->n;
     if (m) *m = lib->m;
-    if (n_passes) *n_passes = (int)lib->passes.size();
-    if (motifs_per_pass) *motifs_per_pass = lib->passes.empty() ? 0 : lib->passes[0].nmp;
+    if (n_passes) *n_passes = lib->has_letters ? (int)lib->passes.size() : 1;
+    if (motifs_per_pass) *motifs_per_pass = !lib->has_letters ? lib->n : (lib->passes.empty() ? 0 : lib->passes[0].nmp);
     if (max_eps) {
         double mx = 0.0;
         for (double v : lib->eps) mx = std::max(mx, v);
@@ -250,6 +285,18 @@ int pfmscan_library_info(const pfmscan_library *lib, int *n_motifs, int *m, int 
 static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const double *thr_seq, const double *thr_struct, hipStream_t st)
 {
     const int n = lib->n, npair = lib->npair;
+    if (!lib->has_letters) {                              // structure-only: the thresholds are the only per-call table
+        for (int k = 0; k < n; ++k)
+            if (std::isnan(thr_struct[k])) return lib_fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
+        if (lib->thr_valid && std::equal(thr_struct, thr_struct + n, lib->cur_struct.begin())) return PFMSCAN_OK;
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        lib->h_thr.assign(thr_struct, thr_struct + n);
+        HIP_TRY(ctx, hipMemcpyAsync(lib->d_thr, lib->h_thr.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        lib->cur_struct.assign(thr_struct, thr_struct + n);
+        lib->eps.assign((size_t)n, 0.0);
+        lib->thr_valid = true;
+        return PFMSCAN_OK;
+    }
     for (int k = 0; k < n; ++k) {
         if (std::isnan(thr_seq[k]) || (lib->has_struct && std::isnan(thr_struct[k]))) return lib_fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
         if (thr_seq[k] == -INFINITY)
@@ -312,6 +359,28 @@ struct LibSink {
 static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile, int profile_dtype,
                    int64_t n_pos, const LibSink &sink, hipStream_t st)
 {
+    if (!lib->has_letters) {
+        ProfLibArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.profile = d_profile;
+        a.profile_dtype = profile_dtype;
+        a.n_pos = n_pos;
+        a.pssm = lib->d_pssm_rows;
+        a.thr = lib->d_thr;
+        a.finite = lib->d_finite;
+        a.n_motifs = lib->n;
+        a.m = lib->m;
+        a.motif_base = 0;
+        a.shard_cap = sink.shard_cap;
+        a.hit_shards = sink.shards;
+        a.hit_pos = sink.pos;
+        a.hit_motif = sink.motif;
+        a.hit_struct = sink.st;
+        a.hit_count = sink.count;
+        hipError_t e = launch_profile_library(a, st);
+        if (e != hipSuccess) return fail_hip(ctx, e, "launch k_profile_lib");
+        return PFMSCAN_OK;
+    }
     const int64_t max_span = (int64_t)1 << 31;
     for (int64_t base = 0; base < n_pos; base += max_span) {
         for (const LibPass &ps : lib->passes) {
@@ -355,8 +424,8 @@ static int lib_check(pfmscan_ctx *ctx, const pfmscan_library *lib, const uint8_t
     if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
     if (lib->ctx != ctx) return lib_fail(ctx, PFMSCAN_E_BADARG, "library belongs to another ctx");
     if (n_pos < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
-    if (!thr_seq || (lib->has_struct && !thr_struct)) return lib_fail(ctx, PFMSCAN_E_BADARG, "threshold arrays are NULL");
-    if (n_pos > 0 && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if ((lib->has_letters && !thr_seq) || (lib->has_struct && !thr_struct)) return lib_fail(ctx, PFMSCAN_E_BADARG, "threshold arrays are NULL");
+    if (n_pos > 0 && lib->has_letters && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
     if (lib->has_struct) {
         if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
             return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs: profile_dtype must be F32 or F64");
@@ -365,11 +434,11 @@ static int lib_check(pfmscan_ctx *ctx, const pfmscan_library *lib, const uint8_t
     return PFMSCAN_OK;
 }
 
-static int lib_scratch(pfmscan_ctx *ctx, int64_t capacity, int64_t n_pos, LibSink &sink)
+static int lib_scratch(pfmscan_ctx *ctx, int64_t capacity, int64_t n_pos, LibSink &sink, int64_t work_unit = LIB_SEG)
 {
     // shard s = workgroup & 255 gets every 256th 16k-window segment: the shards in use fill evenly, each has room for
     // twice its share (short streams use few shards, small capacities let every shard take everything)
-    const int64_t active = std::max<int64_t>(1, std::min<int64_t>(LIB_SHARDS, (n_pos + LIB_SEG - 1) / LIB_SEG));
+    const int64_t active = std::max<int64_t>(1, std::min<int64_t>(LIB_SHARDS, (n_pos + work_unit - 1) / work_unit));
     const int64_t shard_cap = std::max<int64_t>(std::min<int64_t>(capacity, capacity / active * 2 + 1024), 1);
     const size_t slots = (size_t)shard_cap * LIB_SHARDS;
     int rc;
@@ -468,7 +537,7 @@ int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
     LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink))) return rc;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
     const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
     HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
     if ((rc = lib_run(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, sink, st))) return rc;
@@ -479,8 +548,8 @@ int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8
     if (capacity > 0) {
         const int64_t most = std::min<int64_t>(capacity, sink.shard_cap * LIB_SHARDS);
         hipLaunchKernelGGL(k_lib_pack, dim3((unsigned)((most + PACK_BLOCK - 1) / PACK_BLOCK)), dim3(PACK_BLOCK), 0, st, starts,
-                           LIB_SHARDS, sink.shard_cap, capacity, sink.pos, sink.motif, sink.seq, lib->has_struct ? sink.st : nullptr,
-                           d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct);
+                           LIB_SHARDS, sink.shard_cap, capacity, sink.pos, sink.motif, lib->has_letters ? sink.seq : nullptr,
+                           lib->has_struct ? sink.st : nullptr, d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct);
         HIP_TRY(ctx, hipGetLastError());
     }
     return PFMSCAN_OK;
@@ -493,7 +562,7 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     if (!n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
     if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
     if (ctx->staged_n < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "no stream staged (call pfmscan_stage first)");
-    if (!ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
+    if (lib->has_letters && !ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
     if (lib->has_struct && !ctx->staged_profile && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but no profile is staged");
     const int64_t n_pos = ctx->staged_n;
     int rc = lib_check(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq, thr_struct);
@@ -506,7 +575,7 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     hipStream_t st = ctx->stream;
     if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
     LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink))) return rc;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
     const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
     HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
     if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, sink, st))) return rc;
@@ -541,7 +610,7 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     if ((rc = ensure(ctx, ctx->sort_motif, total * 4))) return rc;
     GatherArgs g;
     g.hit_pos = sink.pos;
-    g.hit_seq = sink.seq;
+    g.hit_seq = lib->has_letters ? sink.seq : nullptr;
     g.hit_struct = lib->has_struct ? sink.st : nullptr;
     g.counts = sink.count;
     g.shards = LIB_SHARDS;
@@ -565,10 +634,11 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     }
     HIP_TRY(ctx, hipMemcpyAsync(hit_pos, g.keys_out, total * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(hit_motif, g.motif_out, total * 4, hipMemcpyDeviceToHost, st));
-    if (hit_seq) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, st));
+    if (hit_seq && lib->has_letters) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, st));
     if (hit_struct && lib->has_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (hit_struct && !lib->has_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
+    if (hit_seq && !lib->has_letters) std::fill(hit_seq, hit_seq + total, NAN);
     return PFMSCAN_OK;
 }
 
@@ -580,9 +650,9 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib, const uint
     if (n_pos < 0 || capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
     *n_hits = 0;
     if (n_pos == 0) return PFMSCAN_OK;
-    if (!codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (lib->has_letters && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
     if (lib->has_struct && !profile) return lib_fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
-    int rc = pfmscan_stage(ctx, codes, lib->has_struct ? profile : nullptr, profile_dtype, n_pos);
+    int rc = pfmscan_stage(ctx, lib->has_letters ? codes : nullptr, lib->has_struct ? profile : nullptr, profile_dtype, n_pos);
     if (rc) return rc;
     return pfmscan_library_hits_staged(ctx, lib, thr_seq, thr_struct, capacity, hit_pos, hit_motif, hit_seq, hit_struct, n_hits);
 }

@@ -88,12 +88,13 @@ class HipEngine(object):
 
 
 def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None):
-    """hits of EVERY motif of a library in one pass over the stream (k_library): letter_tables [n][m][8],
-    struct_pssms [n][m][7] or None, thresholds scalar or [n] -> (pos, motif index, seq float32, struct float64 | None)
-    sorted by (pos, motif index)"""
-    T = np.ascontiguousarray(letter_tables, dtype=np.float64)
+    """hits of EVERY motif of a library in one pass over the stream: letter_tables [n][m][8] or None,
+    struct_pssms [n][m][7] or None, thresholds scalar or [n] -> (pos, motif index, seq float32 | None,
+    struct float64 | None) sorted by (pos, motif index).  With letter tables: k_library; structure PSSMs alone:
+    k_profile_lib (the profile is read once, whatever the library's size)."""
+    T = None if letter_tables is None else np.ascontiguousarray(letter_tables, dtype=np.float64)
     P = None if struct_pssms is None else np.ascontiguousarray(struct_pssms, dtype=np.float64)
-    key = (T.shape, T.tobytes(), None if P is None else P.tobytes())
+    key = ((T if T is not None else P).shape, None if T is None else T.tobytes(), None if P is None else P.tobytes())
     if self._library is None or self._library[0] != key:
         if self._library is not None:
             self._library[1].close()
@@ -302,16 +303,35 @@ def struct_matrix(pm, file_letters, pairing="aligned"):
 
 
 def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing, columns=False):
-    """hit table of a packed profile stream (no codes): rnascan.py:302-315 for every record
-    (and for every motif of a library; the stream is staged on the device once)"""
+    """hit table of a packed profile stream (no codes): rnascan.py:302-315 for every record.  A library (several
+    motifs, pfmutil.py:89-133) with a finite threshold is ONE pass per PFM width over the profile (k_profile_lib),
+    instead of the reference's one scan_averaged_structure call per motif; the stream is staged on the device once."""
     tables = []
-    for motif_id, pm in pssm.items():
-        m = pm.length
-        P = struct_matrix(pm, list(letters), pairing)
-        pos, _, st = _select(engine, stream, m, None, P, -np.inf, float(minscore))
+    thr = float(minscore)
+
+    def rows(motif_ids, m, pos, mo, st):
         rec, start = stream.locate(pos)
-        tables.append({"_rec": rec, "Sequence_ID": table.Indexed(ids, rec), "Description": "", "Motif_ID": motif_id,
-                       "Start": start + 1, "End": start + m, "Sequence": ".", "LogOdds": st})
+        ok = start + m <= stream.lengths[rec]                 # no codes -> no separators: drop windows that run over a record end
+        if not ok.all():
+            pos, st, rec, start = pos[ok], st[ok], rec[ok], start[ok]
+            mo = None if mo is None else mo[ok]
+        return {"_rec": rec, "Sequence_ID": table.Indexed(ids, rec), "Description": "",
+                "Motif_ID": motif_ids[0] if mo is None else table.Indexed(motif_ids, mo),
+                "Start": start + 1, "End": start + m, "Sequence": ".", "LogOdds": st}
+
+    by_width = {}
+    for motif_id in sorted(pssm.keys()) if len(pssm) > 1 else list(pssm.keys()):
+        by_width.setdefault(pssm[motif_id].length, []).append(motif_id)
+    for m, mids in by_width.items():
+        if len(mids) > 1 and np.isfinite(thr) and hasattr(engine, "library_hits"):
+            P = np.stack([struct_matrix(pssm[i], list(letters), pairing) for i in mids])
+            pos, mo, _, st = engine.library_hits(stream, None, P, None, thr)
+            tables.append(rows(mids, m, pos, mo, st))
+            continue
+        for motif_id in mids:
+            P = struct_matrix(pssm[motif_id], list(letters), pairing)
+            pos, _, st = _select(engine, stream, m, None, P, -np.inf, thr)      # (drops record-crossing windows itself)
+            tables.append(rows([motif_id], m, pos, None, st))
     return _finish(tables, SEQ_COLUMNS, ["Start", "Motif_ID"], columns)
 
 

@@ -25,7 +25,19 @@ class OracleEngine(object):
 
     def library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None):
         """per-motif oracle scans -> (pos, motif, seq, struct | None) sorted by (pos, motif), like HipEngine.library_hits"""
-        n = letter_tables.shape[0]
+        n = (letter_tables if letter_tables is not None else struct_pssms).shape[0]
+        if letter_tables is None:                            # structure-only library
+            tt = np.broadcast_to(np.asarray(thr_struct, dtype=np.float64), (n,))
+            pos, mo, st_l = [], [], []
+            for k in range(n):
+                st = oracle.stream_struct(stream.profile, struct_pssms[k])
+                p = oracle.stream_hits(None, st, -np.inf, tt[k])
+                pos.append(p)
+                mo.append(np.full(p.size, k, dtype=np.int32))
+                st_l.append(st[p])
+            pos, mo, st_l = np.concatenate(pos), np.concatenate(mo), np.concatenate(st_l)
+            order = np.lexsort((mo, pos))
+            return pos[order], mo[order], None, st_l[order]
         ts = np.broadcast_to(np.asarray(thr_seq, dtype=np.float64), (n,))
         tt = np.broadcast_to(np.asarray(-np.inf if thr_struct is None else thr_struct, dtype=np.float64), (n,))
         pos, mo, sq_l, st_l = [], [], [], []

@@ -341,3 +341,46 @@ def test_native_ingest_path_and_record_path_write_the_same_bytes(tmp_path, monke
         rec = recs[r.Sequence_ID]
         assert r.Description == rec.description
         assert r.Sequence == fasta.preprocess_seq(rec.seq, True)[r.Start - 1:r.End]
+
+
+def test_struct_library_one_pass_equals_per_motif_scans():
+    """structure-only PFM library over profiles: the one-pass library path of _scan_profile_stream gives the table the
+    per-motif loop gives (Motif_ID order inside a Start, windows that run over a record end dropped on the host)"""
+    from collections import OrderedDict
+    from engines import OracleEngine
+    from rnascan_amd import pack, pssm, scanner
+    rng = np.random.default_rng(21)
+    named = []
+    for i in range(11):
+        L = int(rng.integers(3, 120))
+        named.append(("r%d" % i, list("BEHLMRT"), rng.dirichlet(np.full(7, 0.3), size=L)))
+    lib = OrderedDict()
+    for k in (3, 1, 2, 0):                                   # ids out of order: the table sorts by Motif_ID inside a Start
+        m = 6 if k < 3 else 9
+        counts = rng.dirichlet(np.full(7, 0.5), size=m)
+        d = OrderedDict((l, counts[:, c]) for c, l in enumerate(pack.STRUCT_COLUMNS))
+        lib["m%d" % k] = pssm.PSSM(pack.STRUCT_COLUMNS, pssm.log_odds(pssm.normalize(d, 0.01), None))
+
+    import pandas as pd
+    eng = OracleEngine()
+    one_pass = scanner.scan_profiles(eng, named, lib, -6.0, "aligned", np.float64)
+    per_motif = scanner.scan_profiles(_without_library(eng), named, lib, -6.0, "aligned", np.float64)
+    assert len(one_pass) > 30
+    pd.testing.assert_frame_equal(one_pass.reset_index(drop=True), per_motif.reset_index(drop=True))
+    # no window runs over a record end
+    lengths = {n: p.shape[0] for n, _, p in named}
+    assert all(e <= lengths[sid] for sid, e in zip(one_pass["Sequence_ID"], one_pass["End"]))
+
+
+def _without_library(engine):
+    """an engine object that offers no library_hits (forces the per-motif loop)"""
+    class Plain(object):
+        def __init__(self, e):
+            self._e = e
+
+        def scan(self, *a, **k):
+            return self._e.scan(*a, **k)
+
+        def hits(self, *a, **k):
+            return self._e.hits(*a, **k)
+    return Plain(engine)
