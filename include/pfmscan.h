@@ -344,8 +344,9 @@ int pfmscan_profile_parse(const char *buf, int64_t n, int n_cols, int64_t capaci
  * first_match_id >= 0 appends a last column counting up from it.  Every row ends in '\n'; no header line.
  * The rows are written by up to PFMSCAN_TSV_MAX_PIECES threads, each into its own slice of `out` (no intermediate
  * buffer, no copy): afterwards piece k is out[pieces[2k] .. pieces[2k] + pieces[2k + 1]) and the table is the
- * pieces in order, k = 0 .. *n_pieces - 1.  `capacity` must cover n_rows x the longest possible row; *need holds that
- * size (PFMSCAN_E_CAPACITY when capacity is smaller: nothing was written). */
+ * pieces in order, k = 0 .. *n_pieces - 1.  `capacity` must cover the longest the rows can get (a bound per numeric
+ * column, the real lengths of the INDEXED / SPAN values of the rows at hand); *need holds that size
+ * (PFMSCAN_E_CAPACITY when capacity is smaller: nothing was written). */
 #define PFMSCAN_TSV_CONST   0
 #define PFMSCAN_TSV_I64     1
 #define PFMSCAN_TSV_F32     2

@@ -62,8 +62,11 @@ def getoptions(argv=None):
                            "of the reference's -c: its Pool fan-out).  This process then only starts the ranks and waits; "
                            "rank 0 prints the table [1]"))
     gpu.add_argument("--pairing", choices=["aligned", "positional"], default="aligned",
-                     help=("averaged-structure columns vs structure PFM: 'aligned' pairs by letter, 'positional' "
-                           "reproduces the reference on Python 3 (file order BEHLMRT against EHTBLRM) [%(default)s]"))
+                     help=("averaged-structure columns vs structure PFM.  'aligned' pairs every profile column with the PFM "
+                           "row of the SAME letter -- the evident intent, and what the reference computed on Python 2.  "
+                           "NOTE: the reference run on Python >= 3.6 pairs them by POSITION (file order BEHLMRT against the "
+                           "PFM's EHTBLRM, rnascan.py:300-307) and therefore prints different structure scores than this "
+                           "default; '--pairing positional' reproduces those numbers exactly [%(default)s]"))
     gpu.add_argument("--profile-dtype", choices=["float64", "float32"], default="float64",
                      help=("device storage of averaged-structure profiles: float64 reproduces the reference's "
                            "fp64 scores to ~1e-14, float32 halves the HBM traffic and stays within 1e-6 [%(default)s]"))
@@ -116,6 +119,13 @@ def load_motif(pfm_file, pseudocount, letters, background):
     fasta.eprint("Found %d motifs" % len(motifs_set))
     if len(motifs_set) == 0:
         raise ValueError("No motifs found.")
+    from ._lib import MAX_M
+    wide = [(k, v.length) for k, v in motifs_set.items() if v.length > MAX_M]
+    if wide:
+        # the reference's loops take any width (_pwm.c:34-68); the kernels here are unrolled for widths up to PFMSCAN_MAX_M
+        fasta.eprint("PFM %s in %s is %d positions wide: this build scans PFMs of at most %d positions "
+                     "(PFMSCAN_MAX_M, include/pfmscan.h)" % (wide[0][0], pfm_file, wide[0][1], MAX_M))
+        sys.exit(1)
     return motifs_set
 
 

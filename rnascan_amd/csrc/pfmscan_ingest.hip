@@ -462,9 +462,12 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
         return fail(nullptr, PFMSCAN_E_BADARG, "tsv_format: bad argument");
     const int threads = pick_threads(std::min(n_threads > 0 ? n_threads : PFMSCAN_TSV_MAX_PIECES, PFMSCAN_TSV_MAX_PIECES),
                                      (n_rows + 16383) / 16384);                    // a thread is worth starting for ~16k rows
-    // the most bytes a row can take: every thread then owns a slice of `out` it cannot overrun
-    int64_t bound = n_cols + (first_match_id >= 0 ? 21 : 0);
-    std::vector<int64_t> longest((size_t)n_cols, 0);
+    // Every thread owns a slice of `out` it cannot overrun: the most bytes ITS rows can take.  The fixed part of a row is a
+    // bound per column kind; the values of INDEXED / SPAN columns are counted row by row (their real lengths, a doubled
+    // quote for every byte of a span) -- sizing the buffer as rows x the longest value any row uses let ONE 1-kB FASTA header
+    // in a 4 M-row chunk ask for 8 GB.
+    int64_t fixed = n_cols + (first_match_id >= 0 ? 21 : 0);
+    bool any_var = false;
     for (int c = 0; c < n_cols; ++c) {
         const pfmscan_tsv_column &col = cols[c];
         if (col.kind < PFMSCAN_TSV_CONST || col.kind > PFMSCAN_TSV_SPAN || (!col.data && !(col.kind == PFMSCAN_TSV_CONST && col.width == 0)) ||
@@ -472,32 +475,35 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
             ((col.kind == PFMSCAN_TSV_INDEXED || col.kind == PFMSCAN_TSV_WINDOW || col.kind == PFMSCAN_TSV_SPAN) && (!col.aux || !col.blob)))
             return fail(nullptr, PFMSCAN_E_BADARG, "tsv_format: bad column descriptor");
         switch (col.kind) {
-        case PFMSCAN_TSV_CONST: case PFMSCAN_TSV_FIXED: case PFMSCAN_TSV_WINDOW: bound += col.width; break;
-        case PFMSCAN_TSV_I64: bound += 21; break;
-        case PFMSCAN_TSV_F32: case PFMSCAN_TSV_F64: bound += 26; break;
-        default: {                                   // INDEXED / SPAN: the longest value some row uses
-            const int64_t *index = static_cast<const int64_t *>(col.data);
-            const int64_t *aux = static_cast<const int64_t *>(col.aux);
-            std::vector<int64_t> mx((size_t)threads, 0);
-            parallel_ranges(n_rows, threads, [&](int t, int64_t a, int64_t b) {
-                int64_t m = 0;
-                if (col.kind == PFMSCAN_TSV_INDEXED)
-                    for (int64_t r = a; r < b; ++r) m = std::max(m, aux[index[r] + 1] - aux[index[r]]);
-                else
-                    for (int64_t r = a; r < b; ++r) m = std::max(m, 2 * aux[2 * index[r] + 1] + 2);    // every byte a doubled quote
-                mx[(size_t)t] = m;
-            });
-            for (int64_t m : mx) longest[(size_t)c] = std::max(longest[(size_t)c], m);
-            bound += longest[(size_t)c];
-        }
+        case PFMSCAN_TSV_CONST: case PFMSCAN_TSV_FIXED: case PFMSCAN_TSV_WINDOW: fixed += col.width; break;
+        case PFMSCAN_TSV_I64: fixed += 21; break;
+        case PFMSCAN_TSV_F32: case PFMSCAN_TSV_F64: fixed += 26; break;
+        default: any_var = true;
         }
     }
-    *need = n_rows * bound;
+    std::vector<int64_t> room((size_t)threads, 0);
+    parallel_ranges(n_rows, threads, [&](int t, int64_t a, int64_t b) {
+        int64_t var = 0;
+        if (any_var)
+            for (int c = 0; c < n_cols; ++c) {
+                const pfmscan_tsv_column &col = cols[c];
+                const int64_t *index = static_cast<const int64_t *>(col.data);
+                const int64_t *aux = static_cast<const int64_t *>(col.aux);
+                if (col.kind == PFMSCAN_TSV_INDEXED)
+                    for (int64_t r = a; r < b; ++r) var += aux[index[r] + 1] - aux[index[r]];
+                else if (col.kind == PFMSCAN_TSV_SPAN)
+                    for (int64_t r = a; r < b; ++r) var += 2 * aux[2 * index[r] + 1] + 2;    // every byte a doubled quote
+            }
+        room[(size_t)t] = (b - a) * fixed + var;
+    });
+    std::vector<int64_t> start((size_t)threads + 1, 0);
+    for (int t = 0; t < threads; ++t) start[(size_t)t + 1] = start[(size_t)t] + room[(size_t)t];
+    *need = start[(size_t)threads];
     *n_pieces = 0;
     if (*need > capacity) return fail(nullptr, PFMSCAN_E_CAPACITY, "tsv_format: output buffer too small");
     std::vector<int64_t> used((size_t)threads, 0), from((size_t)threads, 0);
     parallel_ranges(n_rows, threads, [&](int t, int64_t a, int64_t b) {
-        char *const base = out + a * bound;
+        char *const base = out + start[(size_t)t];
         char *p = base;
         for (int64_t r = a; r < b; ++r) {
             for (int c = 0; c < n_cols; ++c) {
@@ -560,7 +566,7 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
             }
             *p++ = '\n';
         }
-        from[(size_t)t] = a * bound;
+        from[(size_t)t] = start[(size_t)t];
         used[(size_t)t] = p - base;
     });
     for (int t = 0; t < threads; ++t) {

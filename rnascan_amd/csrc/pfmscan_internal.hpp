@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/pfmscan.h"
 
 namespace pfmscan {
@@ -59,6 +60,22 @@ struct Tuning {
 };
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting of a kernel: `done` (one per kernel
+// instantiation) keeps one bit per device, so a second ctx on another device of the same process gets its attribute
+// too, and two host threads may race here harmlessly (the worst case sets it twice).  Call under the ctx's hipSetDevice.
+inline hipError_t allow_dynamic_lds(const void *kern, std::atomic<uint64_t> &done, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
 
 // Credits of ONE motif at threshold thr (pfmscan_library_api.hip): pairsum [npair][16] exact two-letter sums ->
 // out [npair][16] unsigned 16-bit credits with the threshold folded into row 0; "bit 15 of the sum clear" => the

@@ -1234,13 +1234,17 @@ hipError_t launch_struct_at(const ScanArgs &a, const int64_t *cand_pos, const fl
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-// allow the kernel all of the CU's 160 KB of LDS (static part included)
-static hipError_t allow_full_lds(const void *kern)
+// allow the kernel all of the CU's 160 KB of LDS (static part included); per device, see allow_dynamic_lds
+static hipError_t allow_full_lds(const void *kern, std::atomic<uint64_t> &done)
 {
-    hipFuncAttributes fa;
-    hipError_t e = hipFuncGetAttributes(&fa, kern);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+    if (done.load(std::memory_order_acquire) & (1ull << (dev & 63))) return hipSuccess;     // the usual case: one load
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, kern);
+    if (e != hipSuccess) return e;
+    return allow_dynamic_lds(kern, done, 160 * 1024 - (int)fa.sharedSizeBytes);
 }
 
 // integer position-keyed prefilter (k_letters_cred) for a single 4-letter motif of width <= 32 with a finite threshold;
@@ -1320,12 +1324,9 @@ static hipError_t launch_profile_inst(const ScanArgs &a, hipStream_t stream)
     const unsigned grid = (unsigned)((a.n_pos + L::TILE - 1) / L::TILE);
     const int lds = L::total(a.m, HAS_SEQ, 1);
     auto kern = k_profile<V, HAS_SEQ, PROF_T, FINITE, HITS, DMA>;
-    static bool configured = false;     // per instantiation; the attribute is sticky
-    if (!configured) {
-        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per instantiation, one bit per device
+    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern), configured);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError();
 }

@@ -519,12 +519,9 @@ template <int NG, int NP, typename PROF_T, bool HAS_STRUCT>
 static hipError_t launch_library_inst(const LibArgs &a, unsigned grid, size_t lds, hipStream_t stream)
 {
     auto kern = k_library<NG, NP, PROF_T, HAS_STRUCT>;
-    static bool configured = false;                 // per instantiation; the attribute is sticky
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per instantiation, one bit per device
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), configured, 160 * 1024);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(lib_block(NP)), lds, stream, a);
     return hipGetLastError();
 }

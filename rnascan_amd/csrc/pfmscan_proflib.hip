@@ -31,8 +31,6 @@
 #include <float.h>
 #include <math.h>
 
-#include <atomic>
-
 #include "pfmscan_internal.hpp"
 
 namespace pfmscan {
@@ -271,20 +269,6 @@ __global__ __launch_bounds__(PL_BLOCK) void k_profile_lib(const ProfLibArgs a)
     if (qn > 0) flush();
 }
 
-// hipFuncSetAttribute is per device: one bit per device and kernel instantiation (thread-safe; setting it twice is harmless)
-static hipError_t pl_allow_lds(const void *kern, std::atomic<uint64_t> &done)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    done.fetch_or(bit, std::memory_order_release);
-    return hipSuccess;
-}
-
 int64_t profile_library_tile() { return PL_TILE; }
 
 hipError_t launch_profile_library(const ProfLibArgs &a, hipStream_t stream)
@@ -295,11 +279,11 @@ hipError_t launch_profile_library(const ProfLibArgs &a, hipStream_t stream)
     const size_t lds = (size_t)pl_tile_bytes(a.m) + pl_queue_bytes();
     static std::atomic<uint64_t> done_f{0}, done_d{0};
     if (a.profile_dtype == PFMSCAN_PROFILE_F64) {
-        hipError_t e = pl_allow_lds(reinterpret_cast<const void *>(k_profile_lib<double>), done_d);
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(k_profile_lib<double>), done_d, 160 * 1024);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_profile_lib<double>, dim3(grid), dim3(PL_BLOCK), lds, stream, a);
     } else {
-        hipError_t e = pl_allow_lds(reinterpret_cast<const void *>(k_profile_lib<float>), done_f);
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(k_profile_lib<float>), done_f, 160 * 1024);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_profile_lib<float>, dim3(grid), dim3(PL_BLOCK), lds, stream, a);
     }

@@ -169,12 +169,36 @@ class FastaSlice(object):
         return self.parent._pack(self.lo, self.hi, pack._RNA_LUT)
 
 
+def _has_lone_cr(path):
+    """True when the file holds a carriage return that is not part of \\r\\n (universal newlines make it a line end;
+    the native FASTA index would not).  One memchr pass when the file has no \\r at all -- the usual case."""
+    if not os.path.getsize(path):
+        return False
+    with open(path, "rb") as fh:
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+    try:
+        if mm.find(b"\r") < 0:
+            return False
+        buf = np.frombuffer(mm, dtype=np.uint8)
+        at = np.flatnonzero(buf == 13)
+        nxt = np.minimum(at + 1, buf.size - 1)
+        lone = bool(((buf[nxt] != 10) | (at + 1 >= buf.size)).any())
+        del buf
+        return lone
+    finally:
+        try:
+            mm.close()
+        except BufferError:
+            pass
+
+
 class LazyFasta(object):
     """A FASTA file as a sliceable sequence of Records that holds only an INDEX in memory: header location, byte range
     and letter count per record, from one native pass over the mapped bytes (``pfmscan_fasta_index``).  ``lazy[a:b]``
     is a FastaSlice: a rank of a sharded run (shard.scan_sharded) reads only its own share and a batch only its own
     records -- the reference hands every record to a pool worker through one iterator (rnascan.py:379-395).
-    Compressed input (.gz / .bz2) cannot be mapped: its records are parsed once and kept."""
+    Compressed input (.gz / .bz2) cannot be mapped: its records are parsed once and kept.  So are files with CR-only line
+    ends (old Mac): the native index breaks lines at \\n only, the reference's text-mode reader at any of \\n, \\r\\n, \\r."""
 
     def __init__(self, fasta_files):
         from . import _lib
@@ -188,7 +212,7 @@ class LazyFasta(object):
         self._parsed = {}                      # global record index -> Record (compressed files)
         file_of, local_of, lengths = [], [], []
         for fi, path in enumerate(self.files):
-            if os.path.splitext(path)[1] in (".gz", ".bz2"):
+            if os.path.splitext(path)[1] in (".gz", ".bz2") or _has_lone_cr(path):
                 self._maps.append(None)
                 self._bufs.append(None)
                 self._index.append(None)
@@ -411,7 +435,10 @@ def read_profile(struct_file):
         data = fh.read()
     head = data.split(b"\n", 1)[0].rstrip(b"\r").split(b"\t")
     native = os.environ.get("RNASCAN_PROFILE_PARSER", "native") != "pandas"       # "pandas": A/B of the two parsers
-    if native and len(head) >= 2 and len(set(head)) == len(head) and all(h and h.strip() == h and b'"' not in h for h in head):
+    # the native parser drops the FIRST column; the reference deletes the column NAMED 'PO' (rnascan.py:297), so only a
+    # file whose first column is 'PO' may take it -- any other header is pandas' to judge (below: by name, as the reference)
+    if native and len(head) >= 2 and head[0] == b"PO" and len(set(head)) == len(head) and \
+            all(h and h.strip() == h and b'"' not in h for h in head):
         prof = _lib.profile_parse(data, len(head) - 1)
         if prof is not None and prof.shape[0] > 0:
             return [h.decode("utf-8") for h in head[1:]], prof

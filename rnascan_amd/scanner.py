@@ -69,14 +69,16 @@ class HipEngine(object):
         finally:
             motif.close()
 
-    def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf):
+    def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf, one_shot=True):
         """positions (sorted) whose scores exceed the thresholds -> (pos, seq | None, struct | None).
         A stream that is not on the device yet and is longer than PIPELINE_MIN positions (a memory-mapped profile store,
-        a large batch) goes through the chunked pipeline: upload and scan overlap, device scratch stays two chunks."""
+        a large batch) goes through the chunked pipeline: upload and scan overlap, device scratch stays two chunks --
+        when this is the ONLY scan of the stream (``one_shot``).  A caller that loops over motifs says so: the stream is
+        then staged once for all of them (the pipeline leaves nothing staged, every motif would upload it again)."""
         motif = self.ctx.motif(letter_table, struct_pssm)
         try:
             staged = self._staged is not None and self._staged[0] is stream and self._staged[1] == self.ctx.scratch_gen
-            if not staged and stream.n_pos > PIPELINE_MIN:
+            if one_shot and not staged and stream.n_pos > PIPELINE_MIN:
                 self._staged = None
                 return self.ctx.hits_pipeline_host(motif, stream.codes if letter_table is not None else None,
                                                    stream.profile if struct_pssm is not None else None, thr_seq, thr_struct,
@@ -112,7 +114,7 @@ def _first_motif(pssm):
     return list(pssm.items())[0]
 
 
-def _select(engine, stream, m, letter_table, struct_pssm, thr_seq, thr_struct):
+def _select(engine, stream, m, letter_table, struct_pssm, thr_seq, thr_struct, one_shot=True):
     """hits of a stream; an infinite threshold (-m ' -inf') would make every window
     a hit, so that case takes the all-scores kernel and filters on the host with the
     same strict `>` (NaN and -inf never pass: rnascan.py:263, :310)."""
@@ -125,7 +127,7 @@ def _select(engine, stream, m, letter_table, struct_pssm, thr_seq, thr_struct):
             keep &= st > thr_struct
         pos = np.flatnonzero(keep)
         return pos, (None if sq is None else sq[pos]), (None if st is None else st[pos])
-    pos, sq, st = engine.hits(stream, letter_table, struct_pssm, thr_seq, thr_struct)
+    pos, sq, st = engine.hits(stream, letter_table, struct_pssm, thr_seq, thr_struct, one_shot=one_shot)
     if letter_table is None:                 # no codes -> no separator poisoning: drop windows that
         rec, start = stream.locate(pos)      # run over a record end on the host
         ok = start + m <= stream.lengths[rec]
@@ -260,7 +262,7 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
         for motif_id in mids:
             tab = pssm[motif_id].letter_table(order)
             if is_rna:
-                pos, sq, _ = _select(engine, stream, m, tab, None, float(minscore), -np.inf)
+                pos, sq, _ = _select(engine, stream, m, tab, None, float(minscore), -np.inf, one_shot=len(pssm) == 1)
                 logodds = np.round(sq, 3)                      # round(np.float32, 3) stays float32 (rnascan.py:273)
             else:
                 full = engine.scan_letters_f64(stream, tab)     # Python floats in the reference: fp64, no f32 cast
@@ -330,7 +332,7 @@ def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing, 
             continue
         for motif_id in mids:
             P = struct_matrix(pssm[motif_id], list(letters), pairing)
-            pos, _, st = _select(engine, stream, m, None, P, -np.inf, thr)      # (drops record-crossing windows itself)
+            pos, _, st = _select(engine, stream, m, None, P, -np.inf, thr, one_shot=len(pssm) == 1)      # (drops record-crossing windows itself)
             tables.append(rows([motif_id], m, pos, None, st))
     return _finish(tables, SEQ_COLUMNS, ["Start", "Motif_ID"], columns)
 
@@ -488,7 +490,7 @@ def _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, st
         else:
             parts = []
             for k in range(len(group)):
-                pos, sq, st = _select(engine, stream, m, tabs[k], pssms[k], thr, thr)
+                pos, sq, st = _select(engine, stream, m, tabs[k], pssms[k], thr, thr, one_shot=len(pairs_m) == 1)
                 parts.append((pos, np.full(pos.size, k, dtype=np.int32), sq, st))
         for pos, mo, sq, st in parts:
             rec, start = stream.locate(pos)

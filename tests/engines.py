@@ -18,7 +18,7 @@ class OracleEngine(object):
     def scan_letters_f64(self, stream, letter_table):
         return oracle.stream_letters_f64(stream.codes, letter_table)
 
-    def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf):
+    def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf, one_shot=True):
         sq, st = self.scan(stream, letter_table, struct_pssm)
         pos = oracle.stream_hits(sq, st, thr_seq, thr_struct)
         return pos, (None if sq is None else sq[pos]), (None if st is None else st[pos])

@@ -240,3 +240,19 @@ def test_tsv_writer_quotes_like_to_csv():
     got = io.StringIO()
     table.write_frame(got, df, match_id=True)
     assert got.getvalue() == want.getvalue()
+
+
+def test_cli_says_why_a_pfm_wider_than_the_kernels_is_refused(tmp_path, capsys):
+    """the reference's loops take any PFM width (_pwm.c:34-68); this build stops at PFMSCAN_MAX_M with a clear message"""
+    import pytest
+    from rnascan_amd import _lib, cli, fasta
+    pfm = tmp_path / "wide.pfm"
+    with open(pfm, "w") as f:
+        f.write("PO\tA\tC\tG\tU\n")
+        for i in range(_lib.MAX_M + 1):
+            f.write("%d\t0.25\t0.25\t0.25\t0.25\n" % i)
+    with pytest.raises(SystemExit) as e:
+        cli.load_motif(str(pfm), 0.01, fasta.RNA, None)
+    assert e.value.code == 1
+    err = capsys.readouterr().err
+    assert "%d positions wide" % (_lib.MAX_M + 1) in err and "at most %d" % _lib.MAX_M in err

@@ -104,6 +104,22 @@ def test_lazy_fasta_over_several_files_and_compressed_input(tmp_path):
     assert [r.seq for r in mixed] == ["ACGU", "GG", "ACGT"]
 
 
+def test_cr_only_line_ends_take_the_record_path(tmp_path):
+    """old-Mac line ends: the reference's text-mode reader breaks lines at a lone \\r, the native index does not -- such a
+    file is left to the parsed-record path (CRLF files stay native)"""
+    p = tmp_path / "mac.fa"
+    p.write_bytes(b">b first\rACGU\rACGU\r>c\rGG\r")
+    lz = fasta.LazyFasta(str(p))
+    want = [(r.id, r.description, r.seq) for r in fasta.parse_sequences(str(p))]
+    assert want == [("b", "b first", "ACGUACGU"), ("c", "c", "GG")]
+    assert [(r.id, r.description, r.seq) for r in lz[0:len(lz)]] == want
+    assert list(lz.lengths) == [8, 2]
+    q = tmp_path / "dos.fa"
+    q.write_bytes(b">b first\r\nACGU\r\nACGU\r\n")
+    assert not fasta._has_lone_cr(str(q)) and fasta._has_lone_cr(str(p))
+    assert [(r.id, r.seq) for r in fasta.LazyFasta(str(q))[0:1]] == [("b", "ACGUACGU")]
+
+
 def test_fasta_index_argument_errors():
     L = _lib.load()
     assert L.pfmscan_fasta_index(None, 5, 0, None, None, None, None, None, None, 0) == _lib.E_BADARG
@@ -193,6 +209,23 @@ def test_tsv_format_capacity_and_bad_descriptors():
     with pytest.raises(ValueError):
         _lib.tsv_format([(_lib.TSV_INDEXED, a, None, None, 0)], a.size)
     assert L.pfmscan_tsv_format(None, 1, 1, -1, None, 0, None, None, None, 0) == _lib.E_BADARG
+
+
+def test_one_long_header_does_not_size_the_row_buffer_for_every_row():
+    """the row buffer is sized from the values the rows really hold: one 100 kB FASTA header among 200 k rows must not ask
+    for rows x 200 kB"""
+    n = 200000
+    blob = b"short" + b"x" * 100000
+    spans = np.array([[0, 5], [5, 100000]], dtype=np.int64)
+    index = np.zeros(n, dtype=np.int64)
+    index[1234] = 1
+    cols = [(_lib.TSV_SPAN, index, spans, blob, 0), (_lib.TSV_I64, np.arange(n, dtype=np.int64), None, None, 0)]
+    box = [None]
+    pieces = _lib.tsv_format(cols, n, first_match_id=1, estimate=1 << 16, scratch=box)
+    text = b"".join(bytes(p) for p in pieces)
+    assert box[0].size < 64 << 20                            # (it was n x (2 x 100000 + ...) = 40 GB before)
+    lines = text.split(b"\n")
+    assert len(lines) == n + 1 and lines[0] == b"short\t0\t1" and lines[1234] == b"x" * 100000 + b"\t1234\t1235"
 
 
 def test_background_counts_natively_equal_the_record_loop(tmp_path):
@@ -309,6 +342,8 @@ def test_unusual_profile_files_are_left_to_pandas(tmp_path):
         "nan token": lambda p: _write_profile(p, x, fmt=lambda v: "nan" if v < 0.05 else repr(v)),
         "blank line": lambda p: (_write_profile(p, x), open(p, "a").write("\n\n")),
         "no PO header": lambda p: _write_profile(p, x, header="idx\t" + "\t".join("BEHLMRT")),
+        # 'PO' is deleted BY NAME (rnascan.py:297): when it is not the first column, the first column is a letter's
+        "PO in the second column": lambda p: _write_profile(p, x, header="E\tPO\t" + "\t".join("HTBLRM")),
         "exponent forms": lambda p: _write_profile(p, x, fmt=lambda v: "%.6E" % v),
         "plus signs": lambda p: _write_profile(p, x, fmt=lambda v: "+" + repr(v)),
     }

@@ -384,3 +384,34 @@ def _without_library(engine):
         def hits(self, *a, **k):
             return self._e.hits(*a, **k)
     return Plain(engine)
+
+
+def test_motif_loops_say_that_they_rescan_the_stream():
+    """a loop over motifs must not take the one-shot pipeline per motif (it leaves nothing staged: every motif would upload
+    the stream again); a single motif may"""
+    from collections import OrderedDict
+    from engines import OracleEngine
+    from rnascan_amd import pack, pssm, scanner
+    rng = np.random.default_rng(2)
+    named = [("r%d" % i, list("BEHLMRT"), rng.dirichlet(np.full(7, 0.3), size=40)) for i in range(3)]
+
+    def lib(widths):
+        out = OrderedDict()
+        for k, m in enumerate(widths):
+            counts = rng.dirichlet(np.full(7, 0.5), size=m)
+            d = OrderedDict((l, counts[:, c]) for c, l in enumerate(pack.STRUCT_COLUMNS))
+            out["m%d" % k] = pssm.PSSM(pack.STRUCT_COLUMNS, pssm.log_odds(pssm.normalize(d, 0.01), None))
+        return out
+
+    seen = []
+
+    class Spy(OracleEngine):
+        def hits(self, *a, one_shot=True, **k):
+            seen.append(one_shot)
+            return OracleEngine.hits(self, *a, **k)
+
+    scanner.scan_profiles(Spy(), named, lib([6]), -6.0)
+    assert seen == [True]
+    del seen[:]
+    scanner.scan_profiles(Spy(), named, lib([6, 7, 8]), -6.0)          # three widths: three single-motif scans of one stream
+    assert seen == [False, False, False]
