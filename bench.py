@@ -88,6 +88,177 @@ def make_stream(torch, dev, records, length, seed, foreign=0.0, zero_snap=False)
     return codes.view(-1), profile, n_pos
 
 
+def probe_motifs(tabs):
+    """up to 8 motifs spread over a library (their score distributions differ)"""
+    return [tabs[k] for k in range(0, len(tabs), max(1, len(tabs) // 8))][:8]
+
+
+def struct_only_threshold(torch, ctx, tabs, profile, ptype, n_pos, out_st, stream, hit_rate):
+    """structure-only library: the (1 - hit rate) quantile of the structure scores, mean over up to 8 motifs"""
+    probe = probe_motifs(tabs)
+    qs = []
+    for tp in probe:
+        m0 = ctx.motif(None, tp[1])
+        ctx.scan_dev(m0, None, profile.data_ptr(), ptype, n_pos, None, out_st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sel = out_st[torch.isfinite(out_st)]
+        k_top = max(2, int(round(hit_rate * sel.numel())))
+        top = torch.topk(sel, k_top).values              # sorted descending
+        qs.append(0.5 * (float(top[-1]) + float(top[-2])))       # between two scores, never ON one
+        m0.close()
+        del sel, top
+    out_st.zero_()
+    return float(np.mean(qs)), "auto: mean over %d motifs of the (1 - %g) quantile of their structure scores" % (len(probe), hit_rate)
+
+
+def combined_threshold(torch, ctx, motifs, codes, profile, ptype, n_pos, out_seq, out_st, stream, windows, thr_seq, hit_rate):
+    """the structure threshold that makes the COMBINED hit rate ``hit_rate`` at sequence threshold ``thr_seq`` (SURVEY 8d:
+    "threshold chosen for ~1e-4"): a quantile of the structure scores of the windows passing the sequence threshold, pooled
+    over ``motifs`` (open _lib.Motif objects).  Returns (threshold, fraction of windows passing the sequence side, note)."""
+    pooled = []
+    for m0 in motifs:
+        ctx.scan_dev(m0, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, out_seq.data_ptr(), out_st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sel = out_st[out_seq.double() > thr_seq]
+        pooled.append(sel[torch.isfinite(sel)].clone())
+    sel = torch.cat(pooled)
+    rate_seq = float(sel.numel()) / (windows * len(motifs))
+    keep = min(1.0, hit_rate / max(rate_seq, 1e-30))
+    if sel.numel() == 0:
+        thr = -1e30
+    else:
+        srt, _ = torch.sort(sel)
+        i = min(sel.numel() - 1, int((1.0 - keep) * sel.numel()))
+        # between two scores, never ON one: the kernels' structure sums differ in the last bit (FMA chain vs per-row
+        # sum), and a threshold equal to a score would let that bit decide a hit
+        thr = float(srt[i]) if i == 0 else 0.5 * (float(srt[i - 1]) + float(srt[i]))
+    note = ("auto: quantile of the structure scores of the %.3g of windows with seq > %g (pooled over %d motif%s), for a "
+            "combined rate of %g" % (rate_seq, thr_seq, len(motifs), "s" if len(motifs) > 1 else "", hit_rate))
+    del sel, pooled
+    out_seq.zero_()
+    out_st.zero_()
+    return thr, rate_seq, note
+
+
+def pmc_entry(workload):
+    """counter figures of an earlier rocprofv3 --pmc run of this workload (profiles/pmc_traffic.json), or {}"""
+    try:
+        for tj in json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("entries", []):
+            if tj.get("workload") == workload:
+                return tj
+    except Exception:
+        pass
+    return {}
+
+
+def library_roofline(info, windows, n_motifs, width, records, length, kernel_ms, n_hits, rate_seq):
+    """k_library is bound by LDS look-ups, not by HBM: every window x motif group needs ceil(w/2) 16-byte table entries
+    (ds_read_b128, 256 B/clk/CU).  ``achieved`` = the bytes phase A's look-ups MOVE per second (entries of 12 or 8
+    motifs, padding motifs of the last group included); the nominal 2 B per motif credit is reported beside it, and so
+    is what the counters of an earlier PMC run say about the LDS (the exact pass's gathers come on top of phase A)."""
+    npair = (width + 1) // 2
+    mpg = 12 if width <= 16 else 8
+    groups = sum(-(-min(info["motifs_per_pass"], n_motifs - i * info["motifs_per_pass"]) // mpg) for i in range(info["passes"]))
+    lds_read = float(windows) * groups * npair * 16
+    nominal = float(windows) * n_motifs * npair * 2
+    lds_peak = 256 * 256 * 2.4                      # CUs x B/clk/CU x GHz = GB/s (MI355X_MICROARCH.md, LDS)
+    cand = windows * n_motifs * rate_seq if rate_seq is not None else None
+    pmc = pmc_entry("c5")
+    return {
+        "bound": "lds", "achieved": lds_read / (kernel_ms * 1e-3) / 1e9, "peak": lds_peak, "unit": "GB/s",
+        "frac": lds_read / (kernel_ms * 1e-3) / 1e9 / lds_peak, "traffic": lds_read,
+        "traffic_source": "computed, not measured: 16-byte table entries of %d motifs read by phase A (LDS, not HBM, bytes); "
+                          "the exact pass's gathers come on top" % mpg,
+        "kernel": "k_library (x%d passes of <= %d motifs)" % (info["passes"], info["motifs_per_pass"]),
+        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": lds_read,
+        "algorithmic_unit": "LDS bytes the phase-A look-ups move: windows x motif groups x ceil(w/2) x 16 B",
+        "nominal_2B_per_credit_frac": nominal / (kernel_ms * 1e-3) / 1e9 / lds_peak,
+        "lds_idx_active_frac": pmc.get("lds_idx_active_frac"), "lds_bank_conflict_frac_of_active": pmc.get("lds_bank_conflict_frac"),
+        "counter_source": pmc.get("source"),
+        "hbm_frac": (records * length * info["passes"] + (cand or 0) * width * 28 + (n_hits or 0) * 24)
+                    / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "fp64_tflops_of_73_measured": None if cand is None else cand * width * 14 / (kernel_ms * 1e-3) / 1e12,
+        "prefilter_slack_score_units": info["max_prefilter_eps"],
+    }
+
+
+def timed(torch, fn, steps, warmup):
+    """ms per call of fn over ``steps`` calls after ``warmup`` untimed ones, HIP events on the current torch stream"""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def secondary_legs(torch, _lib, ctx, args, dev, codes, profile, ptype, n_pos, out_seq, out_st, stream, windows):
+    """The other configs of BASELINE.json under the SAME clock as the headline, on the same resident stream, after the
+    headline's timed region: C5 (256 seq+struct PFM pairs, k_library), its structure-only form (k_profile_lib) and C2
+    in hits mode (sequence PFM of width 8 at the CLI's default -m 6, k_letters_cred).  A few steps each, ~2 s in all."""
+    out = {}
+    cap = 1 << 25
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hm = torch.empty(cap, dtype=torch.int32, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    ht = torch.empty(cap, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_lib = 256
+    tabs = [make_pssms(args.width, args.variant, seed=1000 + k) for k in range(n_lib)]
+    # ---- C5
+    motifs = [ctx.motif(*tp) for tp in probe_motifs(tabs)]
+    thr_t, rate_seq, note = combined_threshold(torch, ctx, motifs, codes, profile, ptype, n_pos, out_seq, out_st, stream, windows, 6.0, 1e-4)
+    for m0 in motifs:
+        m0.close()
+    lib = ctx.library(np.stack([t for t, _ in tabs]), np.stack([p for _, p in tabs]))
+
+    def c5():
+        ctx.library_hits_dev(lib, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, 6.0, thr_t, cap, hp.data_ptr(), hm.data_ptr(),
+                             hs.data_ptr(), ht.data_ptr(), cnt.data_ptr(), stream)
+    ms = timed(torch, c5, 3, 1)
+    hits = int(cnt.item())
+    roof = library_roofline(lib.info(), windows, n_lib, args.width, args.records, args.length, ms, hits, rate_seq)
+    out["c5"] = {"workload": "C5: %d seq+struct PFM pairs (w=%d) x the resident stream, k_library" % (n_lib, args.width),
+                 "ms_per_step": ms, "steps": 3, "value": windows * n_lib / (ms * 1e-3), "unit": "window-motif pairs/s",
+                 "hits_per_step": hits, "minscore_seq": 6.0, "minscore_struct": thr_t, "minscore_struct_source": note,
+                 "lds_frac": roof["frac"], "roofline": roof}
+    lib.close()
+    # ---- C5, structure side alone: every motif in one pass over the profile
+    thr_s, note_s = struct_only_threshold(torch, ctx, tabs, profile, ptype, n_pos, out_st, stream, 1e-4)
+    slib = ctx.library(None, np.stack([p for _, p in tabs]))
+
+    def c5s():
+        ctx.library_hits_dev(slib, None, profile.data_ptr(), ptype, n_pos, None, thr_s, cap, hp.data_ptr(), hm.data_ptr(), None,
+                             ht.data_ptr(), cnt.data_ptr(), stream)
+    ms = timed(torch, c5s, 2, 1)
+    tf = float(windows) * n_lib * args.width * 14 / (ms * 1e-3) / 1e12
+    out["c5_struct_only"] = {"workload": "%d structure PFMs (w=%d) x the resident profile in ONE pass, k_profile_lib" % (n_lib, args.width),
+                             "ms_per_step": ms, "steps": 2, "value": windows * n_lib / (ms * 1e-3), "unit": "window-motif pairs/s",
+                             "hits_per_step": int(cnt.item()), "minscore_struct": thr_s, "minscore_struct_source": note_s,
+                             "fp64_tflops": tf, "fp64_frac_of_73_measured": tf / 73.0}
+    slib.close()
+    # ---- C2 hits: sequence PFM of width 8, the CLI's default -m 6
+    t8, _ = make_pssms(8, args.variant)
+    m8 = ctx.motif(t8, None)
+    w8 = args.records * (args.length - 8 + 1)
+
+    def c2():
+        cnt.zero_()
+        ctx.hits_dev(m8, codes.data_ptr(), None, _lib.PROFILE_NONE, n_pos, 6.0, -np.inf, cap, hp.data_ptr(), hs.data_ptr(), None,
+                     cnt.data_ptr(), stream)
+    ms = timed(torch, c2, 20, 3)
+    hits = int(cnt.item())
+    gbs = (args.records * args.length + hits * 12) / (ms * 1e-3) / 1e9
+    out["c2_hits"] = {"workload": "C2 hits: sequence PFM w=8 at -m 6 over the resident codes, k_letters_cred", "ms_per_step": ms, "steps": 20,
+                      "value": w8 / (ms * 1e-3), "unit": "windows/s", "hits_per_step": hits, "minscore_seq": 6.0,
+                      "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    m8.close()
+    return out
+
+
 def dry_run(args, world):
     """PFMSCAN_BENCH_DRYRUN=1: the multi-rank plumbing WITHOUT the hot path -- rank environment, process group (gloo),
     barrier, MAX over ranks, per-rank gather, rank 0's line -- for the launcher test on a machine without a GPU.  No
@@ -147,6 +318,9 @@ def main():
     ap.add_argument("--width", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs of the default line (C5, its structure-only form and C2 hits on the resident "
+                         "stream, after the headline's timed region)")
     ap.add_argument("--no-ref-structured", action="store_true",
                     help="skip the reference-structured Python baseline (B-ref of BASELINE.md section 3)")
     ap.add_argument("--workload", choices=["c3", "c2", "c5", "c5s"], default="c3",
@@ -266,50 +440,14 @@ def main():
     thr_seq, thr_struct, thr_note = args.minscore_seq, args.minscore_struct, "given"
     rate_seq = None
     if struct_lib and thr_struct is None:
-        # structure-only library: the (1 - hit rate) quantile of the structure scores, pooled over up to 8 motifs
-        probe = [tabs[k] for k in range(0, len(tabs), max(1, len(tabs) // 8))][:8]
-        qs = []
-        for tp in probe:
-            m0 = ctx.motif(None, tp[1])
-            ctx.scan_dev(m0, None, profile.data_ptr(), ptype, n_pos, None, out_st.data_ptr(), stream)
-            torch.cuda.synchronize()
-            sel = out_st[torch.isfinite(out_st)]
-            k_top = max(2, int(round(args.hit_rate * sel.numel())))
-            top = torch.topk(sel, k_top).values              # sorted descending
-            qs.append(0.5 * (float(top[-1]) + float(top[-2])))       # between two scores, never ON one
-            m0.close()
-            del sel, top
-        thr_struct = float(np.mean(qs))
-        thr_note = "auto: mean over %d motifs of the (1 - %g) quantile of their structure scores" % (len(probe), args.hit_rate)
-        out_st.zero_()
+        thr_struct, thr_note = struct_only_threshold(torch, ctx, tabs, profile, ptype, n_pos, out_st, stream, args.hit_rate)
     if args.mode != "scores" and not seq_only and thr_struct is None:
-        # pooled over up to 8 motifs of the library (their score distributions differ), or the one motif
-        probe = [tabs[k] for k in range(0, len(tabs), max(1, len(tabs) // 8))][:8] if is_lib else [None]
-        pooled, n_pass = [], 0
-        for tp in probe:
-            m0 = ctx.motif(*tp) if is_lib else motif
-            ctx.scan_dev(m0, codes.data_ptr(), profile.data_ptr(), ptype, n_pos, out_seq.data_ptr(), out_st.data_ptr(), stream)
-            torch.cuda.synchronize()
-            sel = out_st[out_seq.double() > thr_seq]
-            pooled.append(sel[torch.isfinite(sel)].clone())
-            if is_lib:
+        probe = [ctx.motif(*tp) for tp in probe_motifs(tabs)] if is_lib else [motif]
+        thr_struct, rate_seq, thr_note = combined_threshold(torch, ctx, probe, codes, profile, ptype, n_pos, out_seq, out_st, stream,
+                                                            windows, thr_seq, args.hit_rate)
+        if is_lib:
+            for m0 in probe:
                 m0.close()
-        sel = torch.cat(pooled)
-        rate_seq = float(sel.numel()) / (windows * len(probe))
-        keep = min(1.0, args.hit_rate / max(rate_seq, 1e-30))
-        if sel.numel() == 0:
-            thr_struct = -1e30
-        else:
-            srt, _ = torch.sort(sel)
-            i = min(sel.numel() - 1, int((1.0 - keep) * sel.numel()))
-            # between two scores, never ON one: the kernels' structure sums differ in the last bit (FMA chain vs per-row
-            # sum), and a threshold equal to a score would let that bit decide a hit
-            thr_struct = float(srt[i]) if i == 0 else 0.5 * (float(srt[i - 1]) + float(srt[i]))
-        thr_note = ("auto: quantile of the structure scores of the %.3g of windows with seq > %g (pooled over %d motif%s), for a "
-                    "combined rate of %g" % (rate_seq, thr_seq, len(probe), "s" if len(probe) > 1 else "", args.hit_rate))
-        del sel, pooled
-        out_seq.zero_()
-        out_st.zero_()
     if seq_only or thr_struct is None:
         thr_struct = -np.inf if seq_only else thr_struct
 
@@ -520,33 +658,10 @@ def main():
                             / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
         elif is_lib:
-            # The library pass is bound by LDS look-ups, not by HBM: every window x motif needs ceil(w/2) two-byte
-            # credits from the LDS tables (ds_read_b128, 256 B/clk/CU).  Beside it: the HBM fraction (codes once per
-            # pass + the structure rows of the candidates + hits) and the fp64 work of the verification.
-            info = library.info()
-            npair = (args.width + 1) // 2
-            lds_bytes = float(windows) * n_motifs * npair * 2
-            # what the look-ups really move: one 16-byte entry per (window, pair row, motif group); a group holds 12 motifs
-            # (10-bit credits, widths up to 16) or 8 (16-bit credits), padding motifs of the last group included
-            mpg = 12 if args.width <= 16 else 8
-            groups = sum(-(-min(info["motifs_per_pass"], n_motifs - i * info["motifs_per_pass"]) // mpg) for i in range(info["passes"]))
-            lds_read = float(windows) * groups * npair * 16
-            lds_peak = 256 * 256 * 2.4                      # CUs x B/clk/CU x GHz = GB/s (MI355X_MICROARCH.md, LDS)
-            cand = windows * n_motifs * rate_seq if thr_note != "given" else None
-            result["roofline"] = {
-                "bound": "lds", "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": lds_peak, "unit": "GB/s",
-                "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / lds_peak, "traffic": lds_read,
-                "traffic_source": "computed, not measured: 16-byte table entries of %d motifs read by phase A (LDS, not HBM, bytes); "
-                                  "the exact pass's gathers come on top" % mpg,
-                "kernel": "k_library (x%d passes of <= %d motifs)" % (info["passes"], info["motifs_per_pass"]),
-                "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
-                "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": lds_bytes,
-                "algorithmic_unit": "LDS look-up bytes: windows x motifs x ceil(w/2) x 2 B",
-                "hbm_frac": (args.records * args.length * info["passes"] + (cand or 0) * args.width * 28 + (n_hits or 0) * 24)
-                            / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "fp64_tflops_of_73_measured": None if cand is None else cand * args.width * 14 / (kernel_ms * 1e-3) / 1e12,
-                "prefilter_slack_score_units": info["max_prefilter_eps"],
-            }
+            result["roofline"] = library_roofline(library.info(), windows, n_motifs, args.width, args.records, args.length, kernel_ms,
+                                                  n_hits, rate_seq)
+            result["roofline"].update({"kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
+                                       "kernel_ms_max": float(step_ms.max())})
         if dist is None and not args.no_cpu_baseline and args.mode == "scores" and not seq_only:
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             from oracle import oracle
@@ -631,6 +746,11 @@ def main():
                               % (cores, n_seq, t_seq, n_st, t_st),
                 }
                 result["speedup_vs_reference_structured"] = result["value"] / (wpr / per_rec)
+        if (dist is None and not args.no_secondary and args.workload == "c3" and args.mode == "scores" and not args.from_host
+                and args.profile_dtype == "float32"):
+            # last: the legs reuse (and overwrite) the headline's output arrays, whose parity sample has been checked above
+            result["secondary"] = secondary_legs(torch, _lib, ctx, args, dev, codes, profile, ptype, n_pos, out_seq, out_st,
+                                                 stream, windows)
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:
