@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 3
+#define PFMSCAN_ABI_VERSION 4
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -271,6 +271,11 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib,
  * window's score may lie (score units). */
 int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq, int bits,
                                uint16_t *credits, double *slack);
+
+/* The same for the FOUR-letter credit table of the single-motif hits kernel (k_letters_quad, PFMs up to width 32):
+ * credits uint16 [ceil(m/4)][256], entry index c0 | c1 << 2 | c2 << 4 | c3 << 6 over the letters of motif positions
+ * 4t .. 4t+3, 16-bit credits.  A window whose credits sum modulo 2^16 has bit 15 clear cannot be a hit. */
+int pfmscan_debug_quad_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack);
 
 /* How the `_host` / `pfmscan_stage` / pipeline entry points move host memory to the device.
  *   PFMSCAN_UPLOAD_RUNTIME (default): hipMemcpyAsync from the caller's pages; the runtime pins them in place, which

@@ -21,7 +21,7 @@ SEP = 7
 NCODE = 8
 NSTRUCT = 7
 MAX_M = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -31,7 +31,7 @@ SYMBOLS = [
     "pfmscan_scan_host", "pfmscan_scan_letters_f64_host", "pfmscan_hits_host", "pfmscan_time_scan_dev",
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
-    "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table",
+    "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table", "pfmscan_debug_quad_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse",
 ]
@@ -121,6 +121,7 @@ def load():
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, i32, vp, ctypes.POINTER(dbl)]
+    L.pfmscan_debug_quad_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     L.pfmscan_set_upload_mode.argtypes = [vp, i32]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
@@ -675,6 +676,23 @@ def credit_table(letter_table, thr_seq, bits=16):
     rc = L.pfmscan_debug_credit_table(_ptr(T), m, float(thr_seq), int(bits), _ptr(out), ctypes.byref(slack))
     if rc != OK:
         raise ValueError("pfmscan_debug_credit_table: bad argument")
+    return out, slack.value
+
+
+def quad_table(letter_table, thr_seq):
+    """Host-only diagnostic: the four-letter credit table of k_letters_quad for ONE motif (width <= 32) at ``thr_seq``
+    -> (credits uint16 [ceil(m/4)][256], slack in score units).  A window whose credits sum (mod 2**16) has bit 15 clear
+    cannot be a hit."""
+    L = load()
+    T = np.ascontiguousarray(letter_table, dtype=np.float64)
+    if T.ndim != 2 or T.shape[1] != NCODE:
+        raise ValueError("letter_table must be [m][8]")
+    m = T.shape[0]
+    out = np.zeros(((m + 3) // 4, 256), dtype=np.uint16)
+    slack = ctypes.c_double(0.0)
+    rc = L.pfmscan_debug_quad_table(_ptr(T), m, float(thr_seq), _ptr(out), ctypes.byref(slack))
+    if rc != OK:
+        raise ValueError("pfmscan_debug_quad_table: bad argument")
     return out, slack.value
 
 

@@ -98,6 +98,7 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     if (const char *v = std::getenv("PFMSCAN_TILES_PER_BLOCK")) ctx->tune.tiles_per_block = std::max(0, std::min(1024, std::atoi(v)));
     if (const char *v = std::getenv("PFMSCAN_PREFILTER")) ctx->tune.prefilter = std::atoi(v) != 0;
     if (const char *v = std::getenv("PFMSCAN_CREDITS")) ctx->tune.credits = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_QUAD")) ctx->tune.quad = std::atoi(v) != 0;
     *out = ctx;
     return PFMSCAN_OK;
 }
@@ -196,6 +197,15 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
             if (four && m <= 32) {
                 pair_sums(letter_table, m, mo->h_pairsum);
                 mo->has_pairsum = true;
+                mo->h_quadsum = new (std::nothrow) double[(size_t)((m + 3) / 4) * 256];
+                if (mo->h_quadsum) {
+                    quad_sums(letter_table, m, mo->h_quadsum);
+                    if (hipMalloc((void **)&mo->d_quad, 256 * 16) != hipSuccess) {
+                        delete[] mo->h_quadsum;
+                        mo->h_quadsum = nullptr;
+                        mo->d_quad = nullptr;
+                    }
+                }
             }
             if (four) e = hipMalloc((void **)&mo->d_pairs, sizeof(float) * pairs.size());
             if (four && e == hipSuccess) e = hipMemcpy(mo->d_pairs, pairs.data(), sizeof(float) * pairs.size(), hipMemcpyHostToDevice);
@@ -224,6 +234,8 @@ void pfmscan_motif_destroy(pfmscan_motif *mo)
     if (mo->d_letters) (void)hipFree(mo->d_letters);
     if (mo->d_pairs) (void)hipFree(mo->d_pairs);
     if (mo->d_struct) (void)hipFree(mo->d_struct);
+    if (mo->d_quad) (void)hipFree(mo->d_quad);
+    delete[] mo->h_quadsum;
     delete mo;
 }
 
@@ -252,6 +264,10 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.pair_table = ctx->tune.prefilter ? mo->d_pairs : nullptr;
     a.pair_eps = mo->pair_eps;
     a.h_pairsum = mo->has_pairsum ? mo->h_pairsum : nullptr;
+    a.h_quadsum = mo->h_quadsum;
+    a.d_quad = mo->d_quad;
+    a.quad_thr = &mo->quad_thr;
+    a.cred_cache = &mo->cred_cache;
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;

@@ -12,6 +12,10 @@ struct pfmscan_motif {
     double pair_eps = 0.0;
     double h_pairsum[16 * 16];     // exact two-letter sums (m <= 32, 4-letter alphabets): operand of the integer prefilter
     bool has_pairsum = false;
+    double *h_quadsum = nullptr;   // exact four-letter sums [ceil(m/4)][256] (same motifs): operand of k_letters_quad's credits
+    uint32_t *d_quad = nullptr;    // device: the credit table of the threshold quad_thr (rebuilt when the threshold changes)
+    mutable double quad_thr = __builtin_nan("");
+    mutable pfmscan::CredCache cred_cache;
     double *d_struct = nullptr;    // [m][7]
     int m = 0;
     int struct_finite = 0;

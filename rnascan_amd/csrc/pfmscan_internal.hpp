@@ -8,6 +8,14 @@
 
 namespace pfmscan {
 
+// what launch_letters_cred decided for a motif at the last threshold it saw (kept with the motif: building the credits and
+// predicting the survivor rate is host work of a millisecond, the kernel takes a tenth of that)
+struct CredCache {
+    double thr = __builtin_nan("");
+    int mode = 0;                // 1: k_letters_cred with cr; 2: dense threshold -> k_letters_pre; 3: no integer prefilter possible
+    uint16_t cr[16 * 16];
+};
+
 struct ScanArgs {
     const uint8_t *codes;        // [n_pos] device, may be null when the motif has no letter table
     const void *profile;         // [n_pos][7] float or double, device, may be null
@@ -21,6 +29,10 @@ struct ScanArgs {
     double pair_eps;             // |fp32 pair-table score - exact score| <= pair_eps for every window
     const double *h_pairsum;     // HOST: [(m+1)/2][16] exact two-letter sums (4-letter alphabets): the launcher builds the
                                  // integer credit table of k_letters_cred from them for the call's threshold
+    const double *h_quadsum;     // HOST: [(m+3)/4][256] exact four-letter sums (m <= 32): operand of k_letters_quad's credit table
+    uint32_t *d_quad;            // DEVICE: room for that table (256 entries of up to 16 bytes), owned by the motif
+    double *quad_thr;            // HOST: the threshold d_quad currently holds credits for (NaN: none), owned by the motif
+    CredCache *cred_cache;       // HOST: owned by the motif
     const double *struct_pssm;   // [m][7] device or null
     int m;
     int struct_finite;           // every struct_pssm cell finite -> fast path legal
@@ -55,8 +67,11 @@ struct Tuning {
     int prefilter = 1;      // hits over 4-letter alphabets: fp32 two-letter prefilter, exact fp64 re-score of survivors
     int tiles_per_block = 0; // k_letters_pre: 0 = pick from the stream length; > 0 forces it (PFMSCAN_TILES_PER_BLOCK, tests)
     int two_phase = 1;      // combined hits through the host/staged API: letters first, structure only at candidates
-    int credits = 1;        // hits over 4-letter alphabets, m <= 16: integer position-keyed prefilter (k_letters_cred) instead of
+    int credits = 1;        // hits over 4-letter alphabets, m <= 32: integer position-keyed prefilter (k_letters_cred) instead of
                             // the fp32 one (k_letters_pre); PFMSCAN_CREDITS=0 for A/B runs and tests
+    int quad = 0;           // PFMSCAN_QUAD=1: FOUR-letter credit tables (k_letters_quad) instead -- a third of the VALU instructions,
+                            // but its 256-entry look-ups are lane-random over all LDS banks: measured 8-25 % SLOWER at every width
+                            // (profiles/r3/ab_single_motif_hits_kernels.txt); kept for that A/B and covered by the parity tests
 };
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);
@@ -80,8 +95,9 @@ inline hipError_t allow_dynamic_lds(const void *kern, std::atomic<uint64_t> &don
 // Credits of ONE motif at threshold thr (pfmscan_library_api.hip): pairsum [npair][16] exact two-letter sums ->
 // out [npair][16] unsigned 16-bit credits with the threshold folded into row 0; "bit 15 of the sum clear" => the
 // window cannot be a hit.  Returns the one-sided slack in score units (inf: no prefilter possible).  Host code.
-double build_credits(const double *pairsum, int npair, double thr, uint16_t *out, int bits = 16);
+double build_credits(const double *pairsum, int npair, double thr, uint16_t *out, int bits = 16, int nent = 16);
 void pair_sums(const double *letter_table, int m, double *out);      // [m][8] -> [ceil(m/2)][16]
+void quad_sums(const double *letter_table, int m, double *out);      // [m][8] -> [ceil(m/4)][256] four-letter sums
 
 // Second phase of the candidate-then-verify combined scan: structure score of the windows
 // listed in cand_pos[0 .. min(*cand_count, cand_cap)) (hits of a letters-only pass, whose

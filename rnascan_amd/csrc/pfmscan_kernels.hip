@@ -52,6 +52,7 @@
 #include <math.h>
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include "pfmscan_internal.hpp"
 
 namespace pfmscan {
@@ -552,7 +553,6 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     constexpr int NPOS = W + 4 * NJ - 2;               // positions a lane looks up: q = 0 .. W + 4 NJ - 3
     constexpr int NWD = (NPOS + 1 + 3) / 4;            // code dwords holding bytes 0 .. NPOS (the pair at q needs byte q + 1)
     constexpr int ESH = NJ == 1 ? 2 : (NJ == 2 ? 3 : (NJ <= 4 ? 4 : 5));   // log2 of the entry size in bytes
-    constexpr int ZSH = ESH < 4 ? ESH : 4;             // entry offsets travel as bytes (<= 0xF0): 32-byte entries are doubled at use
     constexpr int TROWS = NJ <= 4 ? 16 : 32;           // rows of the exact letter table (rows m .. are zeros)
     constexpr int NWAVE = BLOCK / 64;
     typedef typename CredEntry<NJ>::type entry_t;
@@ -660,23 +660,22 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         if (tile0 >= n_pos) break;                     // uniform; the previous tile flushed (it was the last)
         const uint8_t *cb = cbuf[tb & 1];
         const int off0 = threadIdx.x * W;
-        uint32_t w[NWD + 1];
+        // xm[d] = the low two bits of the four codes at bytes 4d .. 4d+3.  The entry offset of the pair at byte q,
+        // (c[q] | c[q+1] << 2) << ESH, is ONE v_dot4_u32_u8 of that dword with the weights (1, 4) << ESH placed on
+        // bytes q & 3 and (q & 3) + 1 -- plus a v_alignbyte when the pair straddles two dwords.  (Shift / or / mask per
+        // dword and a byte extraction + shift per position were a third of the kernel's VALU instructions.)
+        uint32_t xm[NWD + 1];
 #pragma unroll
-        for (int d = 0; d < NWD + 1; ++d) w[d] = *reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d);   // inside the halo
-        // z[d] byte k = entry offset of the pair at byte 4d+k: (c[4d+k] | c[4d+k+1] << 2) << ZSH  (<= 0xF0)
-        uint32_t z[NWD];
-#pragma unroll
-        for (int d = 0; d < NWD; ++d) {
-            const uint32_t x0 = (w[d] & 0x03030303u) << ZSH, x1 = (w[d + 1] & 0x03030303u) << ZSH;
-            z[d] = x0 | (__builtin_amdgcn_alignbit(x1, x0, 8) << 2);
-        }
+        for (int d = 0; d < NWD + 1; ++d) xm[d] = *reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d) & 0x03030303u;   // inside the halo
+        constexpr uint32_t WT = (1u << ESH) | (4u << ESH) << 8;       // weights of a pair's two letters
         // one look-up per position; P[w + 2] in the text above is pk[w + 2] here (w = -2 .. W-1)
         uint32_t pk[W + 2];
 #pragma unroll
         for (int i = 0; i < W + 2; ++i) pk[i] = 0u;
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
-            const uint32_t off = ((z[q >> 2] >> ((q & 3) * 8)) & 0xFFu) << (ESH - ZSH);
+            const uint32_t off = (q & 3) == 3 ? __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(xm[(q >> 2) + 1], xm[q >> 2], 3u), WT, 0u, false)
+                                              : __builtin_amdgcn_udot4(xm[q >> 2], WT << (8 * (q & 3)), 0u, false);
             uint32_t dj[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             if constexpr (NJ == 1) {
                 dj[0] = *reinterpret_cast<const entry_t *>(cbytes + off);
@@ -700,6 +699,224 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
 #pragma unroll
         for (int v = 0; v < W; ++v) {
             sum[v] = (pk[v + 2] >> 16) + (pk[v] & 0xFFFFu);
+            any |= sum[v];
+        }
+        // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes and score NaN later)
+        if (__builtin_amdgcn_ballot_w64((any & 0x8000u) != 0)) {
+#pragma unroll
+            for (int v = 0; v < W; ++v) {
+                const bool sv = (sum[v] & 0x8000u) != 0;
+                const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
+                if (sb) {                               // wave-uniform
+                    if (sv) my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = tile0 + off0 + v;
+                    sv_n += __popcll(sb);
+                    if (sv_n >= 64) {                   // the top 64 get their exact score, the rest stays
+                        exact_batch(sv_n - 64, 64);
+                        sv_n -= 64;
+                    }
+                }
+            }
+        }
+
+        // tile boundary: publish the next tile's codes and this wave's queue length, ONE barrier
+        const bool more = tb + 1 < ntile && tile0 + LET_TILE < n_pos;
+        if (!more && sv_n > 0) {                       // last tile of the workgroup: the waiting survivors, then the final flush
+            exact_batch(0, sv_n);
+            sv_n = 0;
+        }
+        if (more) cs.park(cbuf[(tb + 1) & 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) snap[tb & 1][wave] = q_n[wave];
+        __syncthreads();
+        if (tb + 2 < ntile && tile0 + 2 * (int64_t)LET_TILE < n_pos) cs.fetch(a.codes, tile0 + 2 * (int64_t)LET_TILE, n_pos);
+        int nq[NWAVE], total = 0, most = 0, before = 0;
+#pragma unroll
+        for (int k = 0; k < NWAVE; ++k) {
+            nq[k] = snap[tb & 1][k];
+            if (k < wave) before += nq[k];
+            total += nq[k];
+            most = most > nq[k] ? most : nq[k];
+        }
+        qn_ub = nq[wave];
+        if (most >= WQ_CAP / 2 || (!more && total > 0)) {          // uniform: every thread read the same snapshot
+            if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)total);
+            __syncthreads();
+            drain(s_base + (unsigned long long)before, nq[wave]);
+            qn_ub = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_letters_quad -- k_letters_cred with FOUR-letter credit tables (PFMs up to width 32, 4-letter alphabet, finite threshold).
+//
+// k_letters_cred is VALU-issue bound (14 instructions per window at w = 8: one table look-up per POSITION, but every
+// look-up brings ceil(m/2)/2 dwords to add, and every position's index costs three bit operations).  Here a table
+// entry covers four motif positions: entry[idx] for the 4-mer idx = c0 | c1 << 2 | c2 << 4 | c3 << 6 holds the credit of
+// EVERY quad row t (motif positions 4t .. 4t+3), two rows per dword, ceil(m/4) rows in all (host: quad_sums +
+// build_credits, same one-sided rounding, threshold folded into row 0, "may be a hit" = bit 15 of the sum):
+//   * half the rows: w = 8 has TWO, one dword per entry -- sum(w) = lo(e[w]) + hi(e[w + 4]) is ONE v_add (SDWA), nothing
+//     to accumulate; wider PFMs add one dword per 8 motif positions (PK[w] = sum_s dword_s(e[w + 8 s + 4]),
+//     sum(w) = hi(PK[w]) + lo(PK[w - 4]));
+//   * the index of the 4-mer at byte position q is ONE v_dot4_u32_u8 of the (pre-scaled) code bytes with the weights
+//     1, 4, 16, 64 -- plus one v_alignbyte when q is not dword aligned -- and arrives already multiplied by the entry size;
+//   * fewer rows also mean finer credits: V = 32767 / (rows - 1) levels, the prefilter keeps next to nothing but hits.
+// The table is 256 entries of 4 / 8 / 16 bytes (1-4 KB of LDS, look-ups lane-random over all banks).  Survivors and hits:
+// as in k_letters_cred (wave-private LDS queues, exact fp64 re-score 64 at a time, one returning atomic per flush).
+// ---------------------------------------------------------------------------
+template <int NQ> struct QuadEntry { typedef u32x4 type; };          // 5..8 quad rows: 16-byte entries
+template <> struct QuadEntry<4> { typedef u32x2 type; };
+template <> struct QuadEntry<3> { typedef u32x2 type; };
+template <> struct QuadEntry<2> { typedef uint32_t type; };
+template <> struct QuadEntry<1> { typedef uint32_t type; };
+
+template <int NQ>
+__global__ __launch_bounds__(BLOCK) void k_letters_quad(const ScanArgs a)
+{
+    constexpr int W = 16;                              // windows per lane = one round per tile
+    constexpr int LET_TILE = BLOCK * W;
+    constexpr int ND = (NQ + 1) / 2;                   // dwords of an entry that carry credits
+    constexpr int ESH = NQ <= 2 ? 2 : (NQ <= 4 ? 3 : 4);   // log2 of the entry size in bytes
+    constexpr int NPOS = W + 4 * (NQ - 1);             // positions a lane looks up: q = 0 .. W + 4 NQ - 5
+    constexpr int NWD = (NPOS + 3 + 3) / 4;            // code dwords holding bytes 0 .. NPOS + 2 (the 4-mer at q ends at q + 3)
+    constexpr int TROWS = NQ <= 4 ? 16 : 32;           // rows of the exact letter table (rows m .. are zeros)
+    constexpr int NWAVE = BLOCK / 64;
+    typedef typename QuadEntry<NQ>::type entry_t;
+    __shared__ __align__(16) double tbl[TROWS * 8];
+    __shared__ __align__(16) uint32_t qtab[256 << (ESH - 2)];
+    __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
+    __shared__ int64_t q_pos[NWAVE][WQ_CAP];
+    __shared__ float q_sc[NWAVE][WQ_CAP];
+    __shared__ int q_n[NWAVE], snap[2][NWAVE];
+    __shared__ unsigned long long s_base;
+    __shared__ int64_t sv_pos[NWAVE][128];             // survivors of the prefilter waiting for their exact score
+    const int m = a.m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_pos = a.n_pos;
+    const int ntile = a.tiles_per_block;
+    const int64_t first = (int64_t)blockIdx.x * ntile * LET_TILE;
+    if (first >= n_pos) return;                        // whole workgroup
+
+    CodeStage<LET_TILE> cs;
+    cs.fetch(a.codes, first, n_pos);
+    // rows m .. are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
+    for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
+    for (int i = threadIdx.x; i < (256 << (ESH - 2)); i += BLOCK) qtab[i] = a.d_quad[i];
+    if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
+    cs.park(cbuf[0]);
+    if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
+    __syncthreads();
+
+    const char *qbytes = (const char *)qtab;
+    const int shard = blockIdx.x & (a.hit_shards - 1);
+    const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.capacity;
+    unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
+    int64_t *my_pos = q_pos[wave];
+    float *my_sc = q_sc[wave];
+
+    auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
+        if ((int64_t)slot < a.capacity) {             // capacity is per shard
+            a.hit_pos[shard_off + slot] = pos + a.pos_offset;
+            if (a.hit_seq) a.hit_seq[shard_off + slot] = sc;
+            if (a.hit_struct) a.hit_struct[shard_off + slot] = (double)sc;
+        }
+    };
+    auto drain = [&](unsigned long long base, int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < n; i += 64) store_hit(base + i, my_pos[i], my_sc[i]);
+        if (lane == 0) q_n[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto wave_flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = __builtin_amdgcn_readfirstlane(q_n[wave]);
+        if (n == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned long long)n);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        drain(((unsigned long long)hi << 32) | lo, n);
+    };
+
+    int qn_ub = 0;                                     // wave-uniform upper bound of q_n[wave]
+    int sv_n = 0;                                      // wave-uniform length of the survivor queue (< 64 between windows)
+    int64_t *my_sv = sv_pos[wave];
+    // exact score of survivors [at, at + cnt) of this wave's queue, one per lane (_pwm.c:34-68)
+    auto exact_batch = [&](int at, int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (qn_ub + cnt > WQ_CAP) {                    // room for a hit per lane in the hit queue
+            wave_flush();
+            qn_ub = 0;
+        }
+        qn_ub += cnt;
+        if (lane < cnt) {
+            const int64_t p = my_sv[at + lane];
+            const int64_t al = p & ~(int64_t)3;
+            uint32_t raw[NQ + 1];
+#pragma unroll
+            for (int k = 0; k < NQ + 1; ++k) raw[k] = load_codes4(a.codes, al + 4 * k, n_pos);
+            double sc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const uint32_t cw = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) sc += tbl[(4 * k + b) * 8 + ((cw >> (8 * b)) & 7u)];      // rows m .. 4 NQ - 1 are zeros
+            }
+            const float f = (float)sc;
+            if ((double)f > a.thr_seq) {
+                const int slot = atomicAdd(&q_n[wave], 1);     // LDS
+                my_pos[slot] = p;
+                my_sc[slot] = f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int tb = 0; tb < ntile; ++tb) {
+        const int64_t tile0 = first + (int64_t)tb * LET_TILE;
+        if (tile0 >= n_pos) break;                     // uniform; the previous tile flushed (it was the last)
+        const uint8_t *cb = cbuf[tb & 1];
+        const int off0 = threadIdx.x * W;
+        // xs[d] byte k = (code at byte 4d + k, its low two bits) << ESH: a foreign letter or separator looks like one of
+        // the four letters here and is rejected by the exact score (NaN), as in k_letters_cred
+        uint32_t xs[NWD + 1];
+#pragma unroll
+        for (int d = 0; d < NWD + 1; ++d)
+            xs[d] = (*reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d) & 0x03030303u) << ESH;       // inside the halo
+        // one look-up per position; PK[w] in the text above is pk[w + 4] here (w = -4 .. W-1)
+        uint32_t pk[W + 4];
+#pragma unroll
+        for (int i = 0; i < W + 4; ++i) pk[i] = 0u;
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q) {
+            const uint32_t by = (q & 3) ? __builtin_amdgcn_alignbyte(xs[(q >> 2) + 1], xs[q >> 2], (uint32_t)(q & 3)) : xs[q >> 2];
+            const uint32_t off = __builtin_amdgcn_udot4(by, 0x40100401u, 0u, false);      // 4-mer index x entry size
+            uint32_t dw[4] = {0u, 0u, 0u, 0u};
+            if constexpr (ND == 1) {
+                dw[0] = *reinterpret_cast<const entry_t *>(qbytes + off);
+            } else {
+                const entry_t e = *reinterpret_cast<const entry_t *>(qbytes + off);
+#pragma unroll
+                for (int s2 = 0; s2 < ND; ++s2) dw[s2] = e[s2];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < ND; ++s2) {
+                const int wi = q - 8 * s2 - 4;         // rows 2 s2 (lo: window wi + 4) and 2 s2 + 1 (hi: window wi)
+                if (wi >= -4 && wi <= W - 1) pk[wi + 4] += dw[s2];
+            }
+        }
+        uint32_t sum[W];
+        uint32_t any = 0;
+#pragma unroll
+        for (int v = 0; v < W; ++v) {
+            sum[v] = (pk[v + 4] >> 16) + (pk[v] & 0xFFFFu);
             any |= sum[v];
         }
         // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes and score NaN later)
@@ -1254,9 +1471,41 @@ static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t 
     if (!(a.hits && a.pair_table && a.h_pairsum && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
     constexpr int CRED_TILE = BLOCK * 16;              // k_letters_cred: 16 windows per lane
     const int npair = (a.m + 1) / 2, nj = (npair + 1) / 2;
-    uint16_t cr[16 * 16];
-    const double slack = build_credits(a.h_pairsum, npair, a.thr_seq, cr);
-    if (!std::isfinite(slack)) return false;
+    CredCache local, *cc = a.cred_cache ? a.cred_cache : &local;
+    if (!(cc->thr == a.thr_seq) || cc->mode == 0) {
+        cc->thr = a.thr_seq;
+        const double slack = build_credits(a.h_pairsum, npair, a.thr_seq, cc->cr);
+        cc->mode = std::isfinite(slack) ? 1 : 3;
+        // Dense thresholds: the queued exact re-score re-reads the survivors' letters (L2) and runs one survivor per lane,
+        // which loses to k_letters_pre's in-place re-score once more than a few per cent of the windows survive (w = 4 at
+        // -m 2: 4.7 % survive, 0.45 against 0.40 ms).  There is no pilot pass on this path, so the survivor rate is
+        // predicted from the credit table itself: the exact distribution of a window's credit sum for independent,
+        // uniformly drawn letters.
+        if (cc->mode == 1) {
+            std::vector<double> dist(65536, 0.0), next(65536, 0.0);
+            dist[0] = 1.0;
+            int top = 0;
+            for (int tr = 0; tr < npair; ++tr) {
+                std::fill(next.begin(), next.end(), 0.0);
+                int ntop = 0;
+                for (int v = 0; v <= top; ++v) {
+                    if (dist[(size_t)v] == 0.0) continue;
+                    for (int i = 0; i < 16; ++i) {
+                        const int w2 = std::min(65535, v + (int)cc->cr[tr * 16 + i]);
+                        next[(size_t)w2] += dist[(size_t)v] * (1.0 / 16.0);
+                        ntop = std::max(ntop, w2);
+                    }
+                }
+                dist.swap(next);
+                top = ntop;
+            }
+            double survive = 0.0;
+            for (int v = 32768; v <= top; ++v) survive += dist[(size_t)v];
+            if (survive > 1.0 / 32.0) cc->mode = 2;
+        }
+    }
+    if (cc->mode != 1) return false;                       // -> k_letters_pre (launch_letters_ndw)
+    const uint16_t *cr = cc->cr;
     CredTable ct;
     std::memset(&ct, 0, sizeof(ct));
     for (int i = 0; i < 16; ++i)
@@ -1275,6 +1524,49 @@ static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t 
     case 6: hipLaunchKernelGGL((k_letters_cred<6>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
     case 7: hipLaunchKernelGGL((k_letters_cred<7>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
     default: hipLaunchKernelGGL((k_letters_cred<8>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    }
+    *err = hipGetLastError();
+    return true;
+}
+
+// four-letter credit tables (k_letters_quad): the table of the call's threshold is built on the host and kept on the
+// device with the motif; it is rebuilt only when the threshold changes
+static bool launch_letters_quad(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
+{
+    if (!(a.hits && a.pair_table && a.h_quadsum && a.d_quad && a.quad_thr && a.m <= 32 && t.credits && t.quad && std::isfinite(a.thr_seq)))
+        return false;
+    constexpr int QUAD_TILE = BLOCK * 16;
+    const int nq = (a.m + 3) / 4, nd = (nq + 1) / 2;
+    const int edw = nq <= 2 ? 1 : (nq <= 4 ? 2 : 4);       // dwords per table entry
+    if (!(*a.quad_thr == a.thr_seq)) {
+        std::vector<uint16_t> cr((size_t)nq * 256);
+        const double slack = build_credits(a.h_quadsum, nq, a.thr_seq, cr.data(), 16, 256);
+        if (!std::isfinite(slack)) return false;           // +inf / NaN four-letter sums: the fp32 prefilter handles those
+        std::vector<uint32_t> tab((size_t)256 * edw, 0u);
+        for (int i = 0; i < 256; ++i)
+            for (int r = 0; r < nq; ++r) tab[(size_t)i * edw + (r >> 1)] |= (uint32_t)cr[(size_t)r * 256 + i] << (16 * (r & 1));
+        (void)nd;
+        // another launch (on any stream) may still read the old table: threshold changes are rare, wait for the device
+        *err = hipDeviceSynchronize();
+        if (*err != hipSuccess) return true;
+        *err = hipMemcpy(a.d_quad, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+        if (*err != hipSuccess) return true;
+        *a.quad_thr = a.thr_seq;
+    }
+    ScanArgs b = a;
+    const int64_t ntiles = (a.n_pos + QUAD_TILE - 1) / QUAD_TILE;
+    b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+    if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
+    const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
+    switch (nq) {
+    case 1: hipLaunchKernelGGL((k_letters_quad<1>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    case 2: hipLaunchKernelGGL((k_letters_quad<2>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    case 3: hipLaunchKernelGGL((k_letters_quad<3>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    case 4: hipLaunchKernelGGL((k_letters_quad<4>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    case 5: hipLaunchKernelGGL((k_letters_quad<5>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    case 6: hipLaunchKernelGGL((k_letters_quad<6>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    case 7: hipLaunchKernelGGL((k_letters_quad<7>), dim3(g), dim3(BLOCK), 0, stream, b); break;
+    default: hipLaunchKernelGGL((k_letters_quad<8>), dim3(g), dim3(BLOCK), 0, stream, b); break;
     }
     *err = hipGetLastError();
     return true;
@@ -1311,6 +1603,7 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
 static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
     hipError_t e = hipSuccess;
+    if (launch_letters_quad(a, t, stream, &e)) return e;     // PFMSCAN_QUAD=1 only: measured slower ("tried")
     if (launch_letters_cred(a, t, stream, &e)) return e;
     if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
     if (a.m <= 32) return launch_letters_ndw<9>(a, t, stream);

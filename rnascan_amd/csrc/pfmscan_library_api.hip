@@ -42,9 +42,10 @@ struct LibPass {
 // Returns the one-sided slack of the prefilter in score units (0 when no window can pass, inf without prefilter).
 }  // namespace
 
-double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint16_t *out, int bits)
+double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint16_t *out, int bits, int nent)
 {
-    std::fill(out, out + (size_t)npair * 16, (uint16_t)0);
+    // (written for rows of 16 two-letter sums; `nent` = 256 makes the same rows of FOUR-letter sums: k_letters_quad)
+    std::fill(out, out + (size_t)npair * nent, (uint16_t)0);
     if (thr == INFINITY) return 0.0;                      // nothing exceeds +inf: all credits 0, the flag bit never set
     const int half = 1 << (bits - 1);                     // the flag bit of a credit sum: 32768 (16-bit) or 512 (10-bit credits)
     const int V = std::min(half - 1, (half - 1) / std::max(npair - 1, 1));
@@ -54,8 +55,8 @@ double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint
     bool special = false;
     for (int t = 0; t < npair; ++t) {
         double mx = 0.0, hi = -INFINITY;
-        for (int i = 0; i < 16; ++i) {
-            const double v = pairsum[t * 16 + i];
+        for (int i = 0; i < nent; ++i) {
+            const double v = pairsum[t * nent + i];
             if (std::isfinite(v)) {
                 mx = std::max(mx, std::fabs(v));
                 hi = std::max(hi, v);
@@ -68,18 +69,18 @@ double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint
         sum_hi += HI[t];
     }
     if (special) {                                        // every window goes to the exact pass
-        for (int i = 0; i < 16; ++i) out[i] = (uint16_t)half;
+        for (int i = 0; i < nent; ++i) out[i] = (uint16_t)half;
         return INFINITY;
     }
-    for (int i = 0; i < 16; ++i) out[i] = (uint16_t)(half - X);
+    for (int i = 0; i < nent; ++i) out[i] = (uint16_t)(half - X);
     const double delta = 0x1p-23 * sum_abs + 1e-9;
     double D = sum_hi - (thr - delta);
     D += 1e-12 * (std::fabs(D) + std::fabs(sum_hi) + std::fabs(thr)) + 1e-300;       // the fp64 evaluation of D itself
     if (!(D > 0.0)) return 0.0;                           // no window can reach the threshold: credits stay 0
     const double q = D / V;
     for (int t = 0; t < npair; ++t)
-        for (int i = 0; i < 16; ++i) {
-            const double e = pairsum[t * 16 + i];
+        for (int i = 0; i < nent; ++i) {
+            const double e = pairsum[t * nent + i];
             int w = 0;
             if (e > -INFINITY) {
                 double deficit = HI[t] - e;
@@ -87,7 +88,7 @@ double pfmscan::build_credits(const double *pairsum, int npair, double thr, uint
                 const double v = std::floor(std::max(deficit, 0.0) / q * (1.0 - 0x1p-40));
                 w = v >= (double)V ? 0 : V - (int)v;
             }
-            out[t * 16 + i] = (uint16_t)(out[t * 16 + i] + w);
+            out[t * nent + i] = (uint16_t)(out[t * nent + i] + w);
         }
     return q * npair;
 }
@@ -101,6 +102,20 @@ void pfmscan::pair_sums(const double *T, int m, double *out)
         for (int c0 = 0; c0 < 4; ++c0)
             for (int c1 = 0; c1 < 4; ++c1)
                 out[t * 16 + (c0 | c1 << 2)] = T[(2 * t) * 8 + c0] + (2 * t + 1 < m ? T[(2 * t + 1) * 8 + c1] : 0.0);
+}
+
+// exact four-letter sums of one letter table [m][8] -> [ceil(m/4)][256], index c0 | c1 << 2 | c2 << 4 | c3 << 6 (positions
+// beyond the width add nothing)
+void pfmscan::quad_sums(const double *T, int m, double *out)
+{
+    const int nq = (m + 3) / 4;
+    for (int t = 0; t < nq; ++t)
+        for (int idx = 0; idx < 256; ++idx) {
+            double v = 0.0;
+            for (int i = 0; i < 4; ++i)
+                if (4 * t + i < m) v += T[(4 * t + i) * 8 + ((idx >> (2 * i)) & 3)];
+            out[t * 256 + idx] = v;
+        }
 }
 
 struct pfmscan_library {
@@ -260,6 +275,17 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
     std::vector<double> ps((size_t)npair * 16);
     pair_sums(letter_table, m, ps.data());
     const double s = build_credits(ps.data(), npair, thr_seq, credits, bits);
+    if (slack) *slack = s;
+    return PFMSCAN_OK;
+}
+
+int pfmscan_debug_quad_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack)
+{
+    if (!letter_table || !credits || m < 1 || m > 32 || std::isnan(thr_seq)) return PFMSCAN_E_BADARG;
+    const int nq = (m + 3) / 4;
+    std::vector<double> qs((size_t)nq * 256);
+    quad_sums(letter_table, m, qs.data());
+    const double s = build_credits(qs.data(), nq, thr_seq, credits, 16, 256);
     if (slack) *slack = s;
     return PFMSCAN_OK;
 }

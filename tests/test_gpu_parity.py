@@ -496,20 +496,23 @@ def test_integer_prefilter_kernel_every_width(ctx, oracle, monkeypatch, m):
     thrs = [1e30, float(fin[-1]), float(fin[int(0.999 * (fin.size - 1))]), float(fin[int(0.97 * (fin.size - 1))]),
             float(np.nextafter(np.float32(fin[int(0.97 * (fin.size - 1))]), np.float32(-np.inf))), 6.0, 0.0, float(fin[0]), -1e30]
     monkeypatch.setenv("PFMSCAN_TILES_PER_BLOCK", "3")
-    cred = _lib.Context(0)
+    cred = _lib.Context(0)                                # default: two-letter credit tables keyed by position (k_letters_cred)
+    monkeypatch.setenv("PFMSCAN_QUAD", "1")
+    quad = _lib.Context(0)                                # four-letter credit tables (k_letters_quad; the A/B variant)
+    monkeypatch.setenv("PFMSCAN_QUAD", "0")
     monkeypatch.setenv("PFMSCAN_CREDITS", "0")
-    plain = _lib.Context(0)
-    m1, m0 = cred.motif(letter_table=T), plain.motif(letter_table=T)
-    for thr in thrs:
+    plain = _lib.Context(0)                               # fp32 prefilter (k_letters_pre)
+    m2, m1, m0 = quad.motif(letter_table=T), cred.motif(letter_table=T), plain.motif(letter_table=T)
+    for thr in thrs + thrs[2:4]:                          # (thresholds come back: the cached table is rebuilt)
         want_pos = oracle.stream_hits(want_seq, None, thr, thr)
-        for c, mo in ((cred, m1), (plain, m0)):
+        for c, mo in ((quad, m2), (cred, m1), (plain, m0)):
             pos, sq, _ = c.hits_host(mo, s.codes, thr_seq=thr)
             assert np.array_equal(pos, want_pos), (m, thr)
             assert_f32_bits_equal(sq, want_seq[want_pos])
-    m1.close()
-    m0.close()
-    cred.close()
-    plain.close()
+    for mo in (m2, m1, m0):
+        mo.close()
+    for c in (quad, cred, plain):
+        c.close()
 
 
 def test_staged_length_follows_the_library_not_a_stale_copy(ctx, oracle):

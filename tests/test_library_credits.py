@@ -94,3 +94,65 @@ def test_wide_motifs_keep_sums_inside_their_fields():
             best = np.concatenate([best, np.zeros((1, m & 1), dtype=best.dtype)], axis=1)
             if float(exact_scores(T, best)[0]) > thr:
                 assert (credit_sums(credits, best, m) & (1 << (used - 1))).all()
+
+
+def quad_sums_of(credits, codes, m):
+    """credit sum of every window under the FOUR-letter tables of k_letters_quad (rows of motif positions 4t .. 4t+3;
+    the last row of a width that is no multiple of 4 also sees the letters AFTER the window)"""
+    nq = (m + 3) // 4
+    tot = np.zeros(codes.shape[0], dtype=np.int64)
+    for t in range(nq):
+        idx = codes[:, 4 * t] | (codes[:, 4 * t + 1] << 2) | (codes[:, 4 * t + 2] << 4) | (codes[:, 4 * t + 3] << 6)
+        tot += credits[t, idx].astype(np.int64)
+    return tot
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("inf_frac", [0.0, 0.2])
+def test_quad_prefilter_never_drops_a_hit(m, inf_frac):
+    """k_letters_quad's table (pfmscan_debug_quad_table): exhaustive over all 4^(4 ceil(m/4)) letter combinations"""
+    rng = np.random.default_rng(77 * m + int(10 * inf_frac))
+    n_letters = 4 * ((m + 3) // 4)
+    codes = all_windows(n_letters)
+    for trial in range(4):
+        T = np.full((m, 8), np.nan)
+        T[:, :4] = rng.normal(0, 2.5, size=(m, 4)) * rng.choice([1.0, 1.0, 30.0])
+        if inf_frac:
+            T[:, :4][rng.random((m, 4)) < inf_frac] = -np.inf
+        f = exact_scores(T, codes)
+        fin = np.sort(f[np.isfinite(f)].astype(np.float64))
+        thrs = [6.0, 0.0, -3.5, 1e4, -1e4, np.inf]
+        if fin.size:
+            thrs += [float(fin[int(q * (fin.size - 1))]) for q in (0.0, 0.5, 0.9, 0.99, 1.0)]            # ON scores
+            thrs += [float(np.nextafter(np.float32(fin[int(0.9 * (fin.size - 1))]), np.float32(-np.inf)))]
+        for thr in thrs:
+            credits, slack = _lib.quad_table(T, thr)
+            tot = quad_sums_of(credits, codes, m)
+            assert tot.max() <= 0xFFFF, "a sum would carry out of its 16-bit half"
+            flagged = (tot & 0x8000) != 0
+            hit = f.astype(np.float64) > thr
+            assert not (hit & ~flagged).any(), "prefilter dropped a hit (m=%d thr=%r)" % (m, thr)
+            if np.isfinite(slack) and flagged.any():
+                kept = f[flagged].astype(np.float64)
+                assert (kept > thr - slack - 1e-5 * (1 + abs(thr)) - 2e-6 * np.abs(T[:, :4][np.isfinite(T[:, :4])]).sum()).all()
+
+
+def test_quad_tables_of_wide_motifs():
+    rng = np.random.default_rng(19)
+    for m in (9, 12, 13, 16, 18, 24, 31, 32):
+        nq = (m + 3) // 4
+        T = np.full((m, 8), np.nan)
+        T[:, :4] = rng.normal(0, 3, size=(m, 4))
+        for thr in (6.0, -50.0, 40.0):
+            credits, slack = _lib.quad_table(T, thr)
+            assert credits.shape == (nq, 256)
+            assert int(credits.max(axis=1).astype(np.int64).sum()) <= 0xFFFF
+            codes = rng.integers(0, 4, size=(200000, 4 * nq))
+            f = exact_scores(T, codes)
+            flagged = (quad_sums_of(credits, codes, m) & 0x8000) != 0
+            assert not ((f.astype(np.float64) > thr) & ~flagged).any()
+            # tighter than the two-letter table of the same motif: fewer rows, finer levels
+            _, slack2 = _lib.credit_table(T, thr, 16)
+            assert slack <= slack2 or not np.isfinite(slack2)
+    with pytest.raises(ValueError):
+        _lib.quad_table(np.full((33, 8), np.nan), 1.0)
