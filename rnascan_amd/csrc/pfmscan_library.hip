@@ -18,8 +18,10 @@
 //      offsets are computed once per window and serve every group, and because the group count NG is a template
 //      parameter every table offset is an immediate of the ds_read.  Windows covering a foreign letter or separator
 //      are dropped here (their exact score is NaN, _pwm.c:61-66).
-//  queue: a flagged (window, motif group) goes to the wave's private LDS queue (position, group, the accumulators' flag
-//      bits): no atomics, waves never synchronise with each other.
+//  queue: flagged windows go to the wave's private LDS queue: no atomics, waves never synchronise with each other.  Twelve
+//      motifs per entry: ONE push per 64-window chunk -- a lane's item is its position, its letters (two bits each) and the
+//      bit mask of its flagged groups (a push per (chunk, group) made phase A VALU-bound: C5 12.9 -> 11.7 ms).  Eight per
+//      entry: an item per (window, group) with the accumulators' flag bits.
 //  phase B (dense, once 64 items wait): one item per lane.  The window's letters are read again (L2); the exact score
 //      is the sequential fp64 sum of _pwm.c:34-68 from an LDS copy of the fp64 letter tables, cast to float32 and compared with the threshold --
 //      only that decides.  A window that passes gets the exact structure score of rnascan.py:302-307
@@ -248,6 +250,34 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
     return g;
 }
 
+// Phase A of the twelve-motifs-per-entry form (widths up to 16): the flags of ALL NG groups of the lane's window as one bit
+// mask.  Nine groups out of ten have a flagged lane somewhere at realistic thresholds, so a push per (chunk, group) -- ballot,
+// branch, slot arithmetic, three LDS stores: ~15 VALU instructions next to the group's 19.5 -- made phase A VALU-bound
+// (+3.9 ms on C5).  Here a group adds one select and one OR; the chunk is pushed ONCE, a lane's item carries its group mask.
+template <int K, int NG, int NP>
+__device__ __forceinline__ uint32_t lib_groupmask(const lds_cptr (&rowp)[NP])
+{
+    uint32_t gm = 0u;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
+        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x20080200u) != 0u;
+        gm |= flag ? (1u << g) : 0u;
+    }
+    return gm;
+}
+
+template <int K, int NG, int NP>
+__device__ __forceinline__ uint32_t lib_dispatch_mask(const int npair, const lds_cptr (&rowp)[NP])
+{
+    if constexpr (K >= NP) {
+        return lib_groupmask<NP, NG, NP>(rowp);
+    } else {
+        if (npair == K) return lib_groupmask<K, NG, NP>(rowp);
+        return lib_dispatch_mask<K + 1, NG, NP>(npair, rowp);
+    }
+}
+
 // npair -> the K-row instantiation, over the pair counts of one width bucket (K = KLO .. NP)
 template <bool FAST, int K, int NG, int NP>
 __device__ __forceinline__ int lib_dispatch(const int npair, const int g, const lds_cptr (&rowp)[NP], int &qn,
@@ -320,13 +350,16 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const int idx = first + (have ? lane : 0);
         const uint32_t rel = q_pos[idx];
         const uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
-        // bits: one per flagged motif of the group; slot_of(bit) = its motif within the group
-        //   8 per entry: byte b, bit 0 = motif b, bit 1 = motif 4 + b;   12 per entry: bit 10 f + d = motif 3 d + f
-        const uint32_t g = MPG == 12 ? ((p0 >> 24) & 0x3Fu) : (p1 & 0x3Fu);
+        // An item of the twelve-per-entry form: p0 = the mask of flagged groups (bits 0-15), p1 = the window's letters.  The
+        // batch works on the LOWEST flagged group g: its credit sums are looked up once more (npair look-ups for 64 items at
+        // once) to see which of its motifs were flagged -- bit 4 f + d of `bits` = motif 3 d + f.  An item that came back
+        // with motifs of g still to do carries them in p0 bits 16-27 under bit 31.
+        // The eight-per-entry form: p0 / p1 = the sign bytes of the accumulators (byte b, bit 0 = motif b, bit 1 = motif
+        // 4 + b) with the group in bits 0-5 of p1.
+        const uint32_t gmask = p0 & 0xFFFFu;
+        const uint32_t g = MPG == 12 ? (uint32_t)__builtin_ctz(gmask | 0x10000u) : (p1 & 0x3Fu);
         uint32_t bits;
         if (MPG == 12) {
-            // a fresh item: its group's credit sums once more (npair look-ups for 64 items at once), flags as below;
-            // an item that came back carries what is left of them
             u32x4 acc = {0u, 0u, 0u, 0u};
             const lds_cptr ent = pairs_lds + g * 256;
             for (int t = 0; t < npair; ++t) {
@@ -337,8 +370,9 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 acc.w += r.w;
             }
             constexpr uint32_t M = 0x20080200u;
-            const uint32_t fresh = ((acc.x & M) >> 9) | ((acc.y & M) >> 8) | ((acc.z & M) >> 7) | ((acc.w & M) >> 6);
-            bits = !have ? 0u : ((p0 & 0x80000000u) ? (p0 & 0x00F03C0Fu) : fresh);
+            const uint32_t spread = ((acc.x & M) >> 9) | ((acc.y & M) >> 8) | ((acc.z & M) >> 7) | ((acc.w & M) >> 6);   // bit 10 f + d
+            const uint32_t fresh = (spread & 0xFu) | ((spread >> 6) & 0xF0u) | ((spread >> 12) & 0xF00u);              // bit 4 f + d
+            bits = !have ? 0u : ((p0 & 0x80000000u) ? ((p0 >> 16) & 0xFFFu) : fresh);
         } else {
             bits = !have ? 0u : (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u));
         }
@@ -346,15 +380,23 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const bool act = bits != 0;
         const int q = act ? __builtin_ctz(bits) : 0;
         bits &= bits - 1;
-        // ONE motif per lane and batch: an item with more flagged motifs goes back to the queue with the rest of its
-        // bits (a second round for the one or two such lanes of a batch would cost as much as a full batch)
-        const unsigned long long more = __builtin_amdgcn_ballot_w64(bits != 0);
+        // ONE motif per lane and batch: an item with more flagged motifs (or, twelve-per-entry, more flagged groups) goes
+        // back to the queue with the rest (a second round for the one or two such lanes of a batch would cost as much as
+        // a full batch)
+        uint32_t back0 = 0u;                             // p0 of the item that goes back (0 = nothing left)
+        if (MPG == 12) {
+            const uint32_t rest = gmask & (gmask - 1u);  // the groups after g
+            back0 = bits != 0 ? (0x80000000u | (bits << 16) | gmask) : rest;
+            if (!have) back0 = 0u;
+        }
+        const bool again = MPG == 12 ? back0 != 0u : bits != 0;
+        const unsigned long long more = __builtin_amdgcn_ballot_w64(again);
         if (more) {
-            if (bits != 0) {
+            if (again) {
                 const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
                 if (MPG == 12) {
-                    q_p0[slot] = bits | (g << 24) | 0x80000000u;
+                    q_p0[slot] = back0;
                     q_p1[slot] = p1;
                 } else {
                     q_p0[slot] = (bits & 0x01010101u) << 7;
@@ -376,7 +418,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 #pragma unroll
             for (int k = 0; k < NP / 2; ++k) w[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
         }
-        const int mo = (int)g * MPG + (MPG == 12 ? 3 * (q % 10) + q / 10 : (q >> 3) + 4 * (q & 1));   // pass-local motif
+        const int mo = (int)g * MPG + (MPG == 12 ? 3 * (q & 3) + (q >> 2) : (q >> 3) + 4 * (q & 1));   // pass-local motif
         // exact sequence score: sequential fp64 sum (_pwm.c:36-64), float32 cast (:65)
         double sc = 0.0;
         const double *L = letters + mo;
@@ -463,14 +505,33 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (dead) rowp[0] = pairs_lds + pair_bytes;
 
             const uint32_t relpos = (uint32_t)(rel0 + lane);
-            int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
-            for (;;) {
+            if constexpr (MPG == 12) {
+                // all groups, then ONE push for the chunk: at most 64 items, and fewer than 64 were waiting -> always room
+                const uint32_t gm = lib_dispatch_mask<1, NG, NP>(npair, rowp);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(gm != 0u);
+                if (mk) {                                    // wave-uniform
+                    if (gm != 0u) {
+                        const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                        q_pos[slot] = relpos;
+                        q_p0[slot] = gm;
+                        q_p1[slot] = cw;
+                    }
+                    qn += __popcll(mk);
+                }
                 while (qn >= 64) {                           // the top 64 items; the rest stays (LIFO)
                     dense(qn - 64, 64);
                     qn += requeued - 64;
                 }
-                if (g >= NG) break;
-                g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+            } else {
+                int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+                for (;;) {
+                    while (qn >= 64) {                       // the top 64 items; the rest stays (LIFO)
+                        dense(qn - 64, 64);
+                        qn += requeued - 64;
+                    }
+                    if (g >= NG) break;
+                    g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+                }
             }
         }
     }
