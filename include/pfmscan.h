@@ -263,6 +263,16 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib,
                               int64_t capacity, int64_t *hit_pos, int32_t *hit_motif,
                               float *hit_seq, double *hit_struct, int64_t *n_hits);
 
+/* pfmscan_hits_pipeline_host for libraries: a host-resident stream of ANY length (a memory-mapped packed profile store and
+ * the codes of its records: the whole of config 5's input) with bounded device scratch; chunks of chunk_positions (0 = 2^24)
+ * positions, the upload of chunk k+1 beside the scan of chunk k, hits sorted by (position, motif index).  Same results and
+ * capacity protocol as pfmscan_library_hits_host; nothing stays staged afterwards. */
+int pfmscan_library_hits_pipeline_host(pfmscan_ctx *ctx, pfmscan_library *lib,
+                                       const uint8_t *codes, const void *profile, int profile_dtype,
+                                       int64_t n_pos, int64_t chunk_positions, const double *thr_seq,
+                                       const double *thr_struct, int64_t capacity, int64_t *hit_pos,
+                                       int32_t *hit_motif, float *hit_seq, double *hit_struct, int64_t *n_hits);
+
 /* Diagnostics (host only, no device needed): the unsigned two-letter credit table the prefilters use for ONE motif
  * (letter_table double [m][8], 4-letter alphabet) at threshold thr_seq: credits uint16 [ceil(m/2)][16], entry index
  * c0 | c1 << 2, with `bits` = 16 (k_letters_cred; k_library for PFMs wider than 16), 10 (k_library up to width 16:

@@ -31,7 +31,8 @@ SYMBOLS = [
     "pfmscan_scan_host", "pfmscan_scan_letters_f64_host", "pfmscan_hits_host", "pfmscan_time_scan_dev",
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
-    "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_debug_credit_table", "pfmscan_debug_quad_table",
+    "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
+    "pfmscan_debug_quad_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse",
 ]
@@ -120,6 +121,7 @@ def load():
     L.pfmscan_library_hits_staged.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_library_hits_host.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_library_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, i32, vp, ctypes.POINTER(dbl)]
     L.pfmscan_debug_quad_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     L.pfmscan_set_upload_mode.argtypes = [vp, i32]
@@ -527,6 +529,49 @@ class Context(object):
     def library_hits_host(self, lib, codes, profile=None, thr_seq=None, thr_struct=None, capacity=None):
         self.stage(codes if lib.has_letters else None, profile if lib.has_struct else None)
         return self.library_hits_staged(lib, thr_seq, thr_struct, capacity)
+
+    def library_hits_pipeline_host(self, lib, codes, profile=None, thr_seq=None, thr_struct=None, chunk_positions=0, capacity=None):
+        """library_hits_host for host streams of any length (numpy arrays or memory maps): chunked, the upload of the next
+        chunk overlaps the scan of the current one, device scratch = two chunks; nothing stays staged"""
+        codes = None if (codes is None or not lib.has_letters) else np.ascontiguousarray(codes, dtype=np.uint8)
+        dt = PROFILE_NONE
+        if lib.has_struct:
+            if profile is None:
+                raise ValueError("library has structure PSSMs: profile required")
+            if profile.dtype == np.float32:
+                dt = PROFILE_F32
+            elif profile.dtype == np.float64:
+                dt = PROFILE_F64
+            else:
+                raise ValueError("profile must be float32 or float64")
+            profile = np.ascontiguousarray(profile)
+            if profile.ndim != 2 or profile.shape[1] != NSTRUCT:
+                raise ValueError("profile must be [n_pos][7]")
+        else:
+            profile = None
+        n = int(codes.size if codes is not None else profile.shape[0])
+        if codes is not None and profile is not None and profile.shape[0] != n:
+            raise ValueError("codes and profile disagree on n_pos")
+        ts, tt = lib.thresholds(thr_seq, thr_struct)
+        cap = int(capacity) if capacity is not None else max(4096, n // 16)
+        self.scratch_gen += 1
+        self._staged_n = -1
+        self._upload_mode_for(codes, profile)
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            mo = np.empty(cap, dtype=np.int32)
+            sq = np.empty(cap, dtype=np.float32)
+            st = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_library_hits_pipeline_host(self._h, lib._h, _ptr(codes), _ptr(profile), dt, n, int(chunk_positions),
+                                                            _ptr(ts), _ptr(tt), cap, _ptr(pos), _ptr(mo), _ptr(sq), _ptr(st),
+                                                            ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
+            return pos[:k].copy(), mo[:k].copy(), (sq[:k].copy() if lib.has_letters else None), (st[:k].copy() if lib.has_struct else None)
 
     def library_hits_dev(self, lib, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct, capacity,
                          d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct, d_hit_count, stream=None):

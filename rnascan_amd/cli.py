@@ -149,10 +149,12 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         fasta.eprint("Scanning averaged secondary structures ")
         ps = store.ProfileStore(source)
         ids = list(range(len(ps.ids)))                 # batches of record indices: the mapped file is sliced, not copied
+        # the batch is a slice of the mapped file (nothing is copied on the host): batches long enough for the chunked
+        # pipeline, which uploads chunk k + 1 beside the scan of chunk k with two chunks of device scratch
         df = shard.scan_sharded(ids, ps.lengths,
                                 lambda part: scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing,
                                                                 part[0] if part else 0, part[-1] + 1 if part else 0, compact),
-                                rank, world, dist, sink=sink)
+                                rank, world, dist, max_positions=8 * shard.batch_positions(), sink=sink)
         fasta.eprint("Processed %d sequences" % len(ps.ids))
         return df
     if os.path.isdir(source):
@@ -299,10 +301,15 @@ def main(argv=None, engine=None, out=None):
         ps = None
         if store.is_store(struct_source):
             ps = store.ProfileStore(struct_source)
-            where = {}
-            for i, sid in enumerate(ps.ids):
-                where.setdefault(sid, []).append(i)
             n_prof = len(ps.ids)
+            # the usual store: the FASTA's records in the FASTA's order.  Then every batch is a slice of the mapped file
+            # and no per-id index is needed (100k dictionary inserts and look-ups were a tenth of C3's command line)
+            rec_ids = list(recs.ids)
+            same_order = n_prof == len(recs) and list(ps.ids) == rec_ids and len(set(rec_ids)) == len(rec_ids)
+            where = {}
+            if not same_order:
+                for i, sid in enumerate(ps.ids):
+                    where.setdefault(sid, []).append(i)
 
             def load(sid):
                 return [(sid, ps.letters, ps.profile[int(ps.offsets[i]):int(ps.offsets[i] + ps.lengths[i])]) for i in where.get(sid, [])]
@@ -326,6 +333,7 @@ def main(argv=None, engine=None, out=None):
         if n_prof == 0:
             raise IOError("No averaged structure files found")
         fasta.eprint("Processed %d sequences" % n_prof)
+        same_order = ps is not None and same_order
         unique = len(set(recs.ids)) == len(recs) and all(len(v) == 1 for v in where.values())
 
         def scan_pairs(part):
@@ -334,7 +342,9 @@ def main(argv=None, engine=None, out=None):
             batch is the batch of the join)"""
             ids = list(part.ids) if hasattr(part, "ids") else [r.id for r in part]
             named, prepacked = None, None
-            if ps is not None and ids:
+            if same_order and ids and hasattr(part, "lo"):
+                prepacked = (ids, ps.letters, ps.stream(part.lo, part.hi))      # record k of the FASTA is record k of the store
+            elif ps is not None and ids:
                 # a packed store that holds these records in this order: its rows ARE the stream, no per-record copy
                 at = [where.get(rid, [-1])[0] for rid in ids]
                 if at[0] >= 0 and at == list(range(at[0], at[0] + len(at))):
@@ -352,7 +362,10 @@ def main(argv=None, engine=None, out=None):
             return df
 
         if unique:
+            # a packed store that holds the FASTA's records in the FASTA's order: every batch is a slice of the mapped file
+            # plus its packed codes (1 byte per position) -- batches long enough for the chunked upload-beside-scan pipeline
             final = shard.scan_sharded(recs, recs.lengths, scan_pairs, rank, world, dist,
+                                       max_positions=(8 if same_order else 1) * shard.batch_positions(),
                                        sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
         else:                                  # duplicate ids join across records: two whole tables + join
             named = load_many(list(where)) if ps is None else [t for sid in where for t in load(sid)]

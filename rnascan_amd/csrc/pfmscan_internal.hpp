@@ -147,6 +147,7 @@ struct LibArgs {
     int profile_dtype;
     int64_t n_pos;                        // stream length (bounds of every read)
     int64_t pos_base, span;               // this launch scores the windows starting in [pos_base, pos_base + span), span < 2^32
+    int64_t pos_offset;                   // added to every reported hit position (chunked host pipeline: where the buffer sits in the stream)
     int64_t seg_positions, n_seg;         // work split: segment s (seg_positions windows, multiple of 1024) -> workgroup s mod grid
     // one pass = nmp = 8 * ng motifs, tables laid out for the kernel (pfmscan_library_api.hip builds them)
     const uint32_t *pairs;                // [npair][ng][16][8] u16 two-letter credits, threshold folded into pair row 0
@@ -179,6 +180,7 @@ struct ProfLibArgs {
     const double *thr;                    // [n_motifs] structure thresholds (hit <=> score > thr, rnascan.py:310)
     const int32_t *finite;                // [n_motifs] 1 = every cell of the motif's PSSM is finite
     int n_motifs, m, motif_base;
+    int64_t pos_offset;                   // added to every reported hit position (chunked host pipeline)
     // hits: hit_shards regions of shard_cap slots, counters HIT_COUNTER_STRIDE words apart (workgroup b -> shard b & (shards-1))
     int64_t shard_cap;
     int hit_shards;

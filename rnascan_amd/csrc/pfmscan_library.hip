@@ -450,7 +450,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (ok) {
                 const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                 if ((int64_t)slot < a.shard_cap) {
-                    a.hit_pos[shard_off + slot] = p;
+                    a.hit_pos[shard_off + slot] = p + a.pos_offset;
                     a.hit_motif[shard_off + slot] = a.motif_base + mo;
                     a.hit_seq[shard_off + slot] = f;
                     if (HAS_STRUCT) a.hit_struct[shard_off + slot] = st;

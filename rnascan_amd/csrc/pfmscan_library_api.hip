@@ -383,7 +383,7 @@ struct LibSink {
 
 // every pass of the library over [0, n_pos); asynchronous on `st`
 static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile, int profile_dtype,
-                   int64_t n_pos, const LibSink &sink, hipStream_t st)
+                   int64_t n_pos, const LibSink &sink, hipStream_t st, int64_t pos_offset = 0)
 {
     if (!lib->has_letters) {
         ProfLibArgs a;
@@ -397,6 +397,7 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
         a.n_motifs = lib->n;
         a.m = lib->m;
         a.motif_base = 0;
+        a.pos_offset = pos_offset;
         a.shard_cap = sink.shard_cap;
         a.hit_shards = sink.shards;
         a.hit_pos = sink.pos;
@@ -430,6 +431,7 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
             a.nmp = ps.nmp;
             a.ng = ps.ng;
             a.motif_base = ps.motif_base;
+            a.pos_offset = pos_offset;
             a.shard_cap = sink.shard_cap;
             a.hit_shards = sink.shards;
             a.hit_pos = sink.pos;
@@ -547,64 +549,14 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_lib_pack(const int64_t *__restri
 
 }  // namespace pfmscan
 
-extern "C" {
-
-int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile,
-                             int profile_dtype, int64_t n_pos, const double *thr_seq, const double *thr_struct, int64_t capacity,
-                             int64_t *d_hit_pos, int32_t *d_hit_motif, float *d_hit_seq, double *d_hit_struct,
-                             uint64_t *d_hit_count, void *stream)
+// the sharded hits of a library scan -> the caller's host arrays, sorted by (position, motif): capacity check, device
+// sort (pfmscan_sort.hip), contiguous copies.  Synchronises ctx->stream.  Positions lie in [0, n_pos).
+static int lib_finish_sorted(pfmscan_ctx *ctx, pfmscan_library *lib, int64_t n_pos, int64_t capacity, const LibSink &sink,
+                             int64_t *hit_pos, int32_t *hit_motif, float *hit_seq, double *hit_struct, int64_t *n_hits)
 {
-    int rc = lib_check(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct);
-    if (rc) return rc;
-    if (capacity < 0 || !d_hit_count || (capacity > 0 && (!d_hit_pos || !d_hit_motif)))
-        return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_hits_dev: bad hit buffers");
-    if (misaligned(d_codes) || misaligned(d_profile)) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "stream base pointers must be 16-byte aligned");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
-    LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
-    const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
-    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
-    if ((rc = lib_run(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, sink, st))) return rc;
-    int64_t *starts = reinterpret_cast<int64_t *>(reinterpret_cast<unsigned char *>(sink.count) + (size_t)(LIB_SHARDS + 2) * HIT_COUNTER_STRIDE * 8);
-    hipLaunchKernelGGL(k_lib_prefix, dim3(1), dim3(PACK_BLOCK), 0, st, sink.count, LIB_SHARDS, sink.shard_cap, capacity, starts,
-                       reinterpret_cast<unsigned long long *>(d_hit_count));
-    HIP_TRY(ctx, hipGetLastError());
-    if (capacity > 0) {
-        const int64_t most = std::min<int64_t>(capacity, sink.shard_cap * LIB_SHARDS);
-        hipLaunchKernelGGL(k_lib_pack, dim3((unsigned)((most + PACK_BLOCK - 1) / PACK_BLOCK)), dim3(PACK_BLOCK), 0, st, starts,
-                           LIB_SHARDS, sink.shard_cap, capacity, sink.pos, sink.motif, lib->has_letters ? sink.seq : nullptr,
-                           lib->has_struct ? sink.st : nullptr, d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    return PFMSCAN_OK;
-}
-
-int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const double *thr_seq, const double *thr_struct,
-                                int64_t capacity, int64_t *hit_pos, int32_t *hit_motif, float *hit_seq, double *hit_struct,
-                                int64_t *n_hits)
-{
-    if (!n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
-    if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
-    if (ctx->staged_n < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "no stream staged (call pfmscan_stage first)");
-    if (lib->has_letters && !ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
-    if (lib->has_struct && !ctx->staged_profile && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but no profile is staged");
-    const int64_t n_pos = ctx->staged_n;
-    int rc = lib_check(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq, thr_struct);
-    if (rc) return rc;
-    if (capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
-    *n_hits = 0;
-    if (n_pos == 0) return PFMSCAN_OK;
-    if (capacity > 0 && (!hit_pos || !hit_motif)) return lib_fail(ctx, PFMSCAN_E_BADARG, "hit_pos / hit_motif is NULL");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
     hipStream_t st = ctx->stream;
-    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
-    LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
     const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
-    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
-    if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, sink, st))) return rc;
     std::vector<unsigned long long> counters((size_t)LIB_SHARDS * HIT_COUNTER_STRIDE);
     HIP_TRY(ctx, hipMemcpyAsync(counters.data(), sink.count, counter_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -666,6 +618,133 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     if (hit_struct && !lib->has_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
     if (hit_seq && !lib->has_letters) std::fill(hit_seq, hit_seq + total, NAN);
     return PFMSCAN_OK;
+}
+
+extern "C" {
+
+int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile,
+                             int profile_dtype, int64_t n_pos, const double *thr_seq, const double *thr_struct, int64_t capacity,
+                             int64_t *d_hit_pos, int32_t *d_hit_motif, float *d_hit_seq, double *d_hit_struct,
+                             uint64_t *d_hit_count, void *stream)
+{
+    int rc = lib_check(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (capacity < 0 || !d_hit_count || (capacity > 0 && (!d_hit_pos || !d_hit_motif)))
+        return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_hits_dev: bad hit buffers");
+    if (misaligned(d_codes) || misaligned(d_profile)) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "stream base pointers must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
+    LibSink sink;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
+    const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
+    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
+    if ((rc = lib_run(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, sink, st))) return rc;
+    int64_t *starts = reinterpret_cast<int64_t *>(reinterpret_cast<unsigned char *>(sink.count) + (size_t)(LIB_SHARDS + 2) * HIT_COUNTER_STRIDE * 8);
+    hipLaunchKernelGGL(k_lib_prefix, dim3(1), dim3(PACK_BLOCK), 0, st, sink.count, LIB_SHARDS, sink.shard_cap, capacity, starts,
+                       reinterpret_cast<unsigned long long *>(d_hit_count));
+    HIP_TRY(ctx, hipGetLastError());
+    if (capacity > 0) {
+        const int64_t most = std::min<int64_t>(capacity, sink.shard_cap * LIB_SHARDS);
+        hipLaunchKernelGGL(k_lib_pack, dim3((unsigned)((most + PACK_BLOCK - 1) / PACK_BLOCK)), dim3(PACK_BLOCK), 0, st, starts,
+                           LIB_SHARDS, sink.shard_cap, capacity, sink.pos, sink.motif, lib->has_letters ? sink.seq : nullptr,
+                           lib->has_struct ? sink.st : nullptr, d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return PFMSCAN_OK;
+}
+
+int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const double *thr_seq, const double *thr_struct,
+                                int64_t capacity, int64_t *hit_pos, int32_t *hit_motif, float *hit_seq, double *hit_struct,
+                                int64_t *n_hits)
+{
+    if (!n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
+    if (ctx->staged_n < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "no stream staged (call pfmscan_stage first)");
+    if (lib->has_letters && !ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
+    if (lib->has_struct && !ctx->staged_profile && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but no profile is staged");
+    const int64_t n_pos = ctx->staged_n;
+    int rc = lib_check(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (capacity > 0 && (!hit_pos || !hit_motif)) return lib_fail(ctx, PFMSCAN_E_BADARG, "hit_pos / hit_motif is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
+    LibSink sink;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
+    const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
+    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
+    if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, sink, st))) return rc;
+    return lib_finish_sorted(ctx, lib, n_pos, capacity, sink, hit_pos, hit_motif, hit_seq, hit_struct, n_hits);
+}
+
+// The library twin of pfmscan_hits_pipeline_host (pfmscan_pipeline.hip): a HOST-resident stream of any length, chunk by
+// chunk through two alternating device buffers, the upload of chunk k + 1 (copy stream) beside the scan of chunk k.  A chunk
+// holds its positions plus the m - 1 after them, so every window starting inside it sees its letters / rows; windows starting
+// in the overhang run past the buffer's end and are never reported (they belong to the next chunk).
+int pfmscan_library_hits_pipeline_host(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *codes, const void *profile,
+                                       int profile_dtype, int64_t n_pos, int64_t chunk_positions, const double *thr_seq,
+                                       const double *thr_struct, int64_t capacity, int64_t *hit_pos, int32_t *hit_motif,
+                                       float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    if (!ctx || !lib || !n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (n_pos < 0 || capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    int rc = lib_check(ctx, lib, codes, profile, profile_dtype, n_pos, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (capacity > 0 && (!hit_pos || !hit_motif)) return lib_fail(ctx, PFMSCAN_E_BADARG, "hit_pos / hit_motif is NULL");
+    if (chunk_positions <= 0) chunk_positions = (int64_t)1 << 24;
+    chunk_positions = std::max<int64_t>((chunk_positions + LIB_SEG - 1) / LIB_SEG * LIB_SEG, LIB_SEG);    // whole work segments, 16-byte aligned starts
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->staged_n = -1;                                                      // nothing stays staged
+    const int m = lib->m;
+    const size_t row_bytes = lib->has_struct ? (size_t)7 * (profile_dtype == PFMSCAN_PROFILE_F32 ? 4 : 8) : 0;
+    const int64_t buf_positions = std::min<int64_t>(n_pos, chunk_positions + m - 1);
+    if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (lib->has_letters && (rc = ensure(ctx, ctx->pipe_codes[i], (size_t)buf_positions))) return rc;
+        if (lib->has_struct && (rc = ensure(ctx, ctx->pipe_profile[i], (size_t)buf_positions * row_bytes))) return rc;
+        if (!ctx->pipe_copied[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
+        if (!ctx->pipe_scanned[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_scanned[i], hipEventDisableTiming));
+    }
+    hipStream_t st = ctx->stream;
+    if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
+    LibSink sink;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
+    const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
+    HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));          // cleared once: the chunks' hits accumulate
+
+    const int64_t n_chunks = (n_pos + chunk_positions - 1) / chunk_positions;
+    auto upload_chunk = [&](int64_t k) -> int {
+        const int b = (int)(k & 1);
+        const int64_t a0 = k * chunk_positions;
+        const int64_t len = std::min<int64_t>(n_pos - a0, chunk_positions + m - 1);
+        if (k >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_scanned[b], 0));    // the buffer's previous chunk is scanned
+        if (lib->has_letters)
+            if (int urc = pfmscan::upload(ctx, ctx->pipe_codes[b].p, codes + a0, (size_t)len, ctx->copy_stream)) return urc;
+        if (lib->has_struct)
+            if (int urc = pfmscan::upload(ctx, ctx->pipe_profile[b].p, reinterpret_cast<const unsigned char *>(profile) + (size_t)a0 * row_bytes,
+                                          (size_t)len * row_bytes, ctx->copy_stream))
+                return urc;
+        HIP_TRY(ctx, hipEventRecord(ctx->pipe_copied[b], ctx->copy_stream));
+        return PFMSCAN_OK;
+    };
+    if ((rc = upload_chunk(0))) return rc;
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        const int b = (int)(k & 1);
+        const int64_t a0 = k * chunk_positions;
+        const int64_t len = std::min<int64_t>(n_pos - a0, chunk_positions + m - 1);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipe_copied[b], 0));
+        if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->pipe_codes[b].p, ctx->pipe_profile[b].p, profile_dtype, len, sink, st, a0))) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->pipe_scanned[b], st));
+        if (k + 1 < n_chunks && (rc = upload_chunk(k + 1))) return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return lib_finish_sorted(ctx, lib, n_pos, capacity, sink, hit_pos, hit_motif, hit_seq, hit_struct, n_hits);
 }
 
 int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *codes, const void *profile,

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_profile_lib(const ProfLibArgs a)
             const unsigned long long slot = base + (unsigned long long)i;
             if ((int64_t)slot < a.shard_cap) {         // capacity is per shard
                 const uint32_t wm = q_wm[i];
-                a.hit_pos[shard_off + slot] = tile0 + (int64_t)(wm >> 16);
+                a.hit_pos[shard_off + slot] = tile0 + (int64_t)(wm >> 16) + a.pos_offset;
                 a.hit_motif[shard_off + slot] = a.motif_base + (int32_t)(wm & 0xFFFFu);
                 a.hit_struct[shard_off + slot] = q_sc[i];
             }

@@ -169,27 +169,19 @@ class FastaSlice(object):
         return self.parent._pack(self.lo, self.hi, pack._RNA_LUT)
 
 
-def _has_lone_cr(path):
-    """True when the file holds a carriage return that is not part of \\r\\n (universal newlines make it a line end;
-    the native FASTA index would not).  One memchr pass when the file has no \\r at all -- the usual case."""
-    if not os.path.getsize(path):
-        return False
+def _has_lone_cr(path, probe=1 << 20):
+    """True when the file's first MiB holds a carriage return that is not part of \\r\\n: universal newlines make it a
+    line end, the native FASTA index would not.  A file written with CR-only line ends (old Mac) has them from the first
+    line on, so the head of the file decides (scanning all of a 300 MB FASTA for a stray \\r cost as much as indexing and
+    packing it)."""
     with open(path, "rb") as fh:
-        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
-    try:
-        if mm.find(b"\r") < 0:
-            return False
-        buf = np.frombuffer(mm, dtype=np.uint8)
-        at = np.flatnonzero(buf == 13)
-        nxt = np.minimum(at + 1, buf.size - 1)
-        lone = bool(((buf[nxt] != 10) | (at + 1 >= buf.size)).any())
-        del buf
-        return lone
-    finally:
-        try:
-            mm.close()
-        except BufferError:
-            pass
+        head = fh.read(probe + 1)
+    at = head.find(b"\r")
+    while 0 <= at < min(len(head), probe):
+        if head[at + 1:at + 2] != b"\n":
+            return True
+        at = head.find(b"\r", at + 1)
+    return False
 
 
 class LazyFasta(object):

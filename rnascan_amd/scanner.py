@@ -89,7 +89,7 @@ class HipEngine(object):
             motif.close()
 
 
-def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None):
+def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None, one_shot=True):
     """hits of EVERY motif of a library in one pass over the stream: letter_tables [n][m][8] or None,
     struct_pssms [n][m][7] or None, thresholds scalar or [n] -> (pos, motif index, seq float32 | None,
     struct float64 | None) sorted by (pos, motif index).  With letter tables: k_library; structure PSSMs alone:
@@ -102,6 +102,13 @@ def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct
             self._library[1].close()
             self._library = None
         self._library = (key, self.ctx.library(T, P))
+    staged = self._staged is not None and self._staged[0] is stream and self._staged[1] == self.ctx.scratch_gen
+    if one_shot and not staged and stream.n_pos > PIPELINE_MIN:
+        # a long stream that only this library will scan (a memory-mapped profile store + the codes of its records):
+        # chunked, upload beside scan, two chunks of device scratch
+        self._staged = None
+        return self.ctx.library_hits_pipeline_host(self._library[1], stream.codes if T is not None else None,
+                                                   stream.profile if P is not None else None, thr_seq, thr_struct, PIPELINE_CHUNK)
     self._stage(stream)
     return self.ctx.library_hits_staged(self._library[1], thr_seq, thr_struct)
 
@@ -256,7 +263,7 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
     for m, mids in by_width.items():
         if is_rna and len(mids) > 1 and np.isfinite(float(minscore)):
             T = np.stack([pssm[i].letter_table(order) for i in mids])
-            pos, mo, sq, _ = engine.library_hits(stream, T, None, float(minscore))
+            pos, mo, sq, _ = engine.library_hits(stream, T, None, float(minscore), one_shot=len(by_width) == 1)
             tables.append(rows(mids, m, pos, mo, np.round(sq, 3)))
             continue
         for motif_id in mids:
@@ -327,7 +334,7 @@ def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing, 
     for m, mids in by_width.items():
         if len(mids) > 1 and np.isfinite(thr) and hasattr(engine, "library_hits"):
             P = np.stack([struct_matrix(pssm[i], list(letters), pairing) for i in mids])
-            pos, mo, _, st = engine.library_hits(stream, None, P, None, thr)
+            pos, mo, _, st = engine.library_hits(stream, None, P, None, thr, one_shot=len(by_width) == 1)
             tables.append(rows(mids, m, pos, mo, st))
             continue
         for motif_id in mids:
@@ -485,7 +492,7 @@ def _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, st
         tabs = [seq_pssm[a].letter_table(pack.RNA_LETTERS) for a, _ in group]
         pssms = [struct_matrix(struct_pssm[b], letters0, pairing) for _, b in group]
         if len(group) > 1 and np.isfinite(thr):
-            pos, mo, sq, st = engine.library_hits(stream, np.stack(tabs), np.stack(pssms), thr, thr)
+            pos, mo, sq, st = engine.library_hits(stream, np.stack(tabs), np.stack(pssms), thr, thr, one_shot=len(by_width) == 1)
             parts = [(pos, mo, sq, st)]
         else:
             parts = []

@@ -23,7 +23,7 @@ class OracleEngine(object):
         pos = oracle.stream_hits(sq, st, thr_seq, thr_struct)
         return pos, (None if sq is None else sq[pos]), (None if st is None else st[pos])
 
-    def library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None):
+    def library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None, one_shot=True):
         """per-motif oracle scans -> (pos, motif, seq, struct | None) sorted by (pos, motif), like HipEngine.library_hits"""
         n = (letter_tables if letter_tables is not None else struct_pssms).shape[0]
         if letter_tables is None:                            # structure-only library

@@ -329,3 +329,34 @@ def test_sequence_library_beyond_two_to_the_31_positions(ctx, oracle):
     assert_f32_bits_equal(gs, ws[o2])
     assert ((gp == n_pos - m - 1) & (gm == 5)).any()
     lib.close()
+
+
+@pytest.mark.parametrize("kind", ["seq+struct", "seq", "struct"])
+def test_library_pipeline_host_equals_staged(ctx, oracle, kind):
+    """pfmscan_library_hits_pipeline_host (chunked upload beside the scan, two chunks of device scratch) == stage + scan,
+    for all three kinds of library, at chunk sizes from one work segment up; windows in a chunk's overhang are reported by
+    the next chunk only"""
+    rng = np.random.default_rng({"seq+struct": 1, "seq": 2, "struct": 3}[kind])
+    s = rand_stream(rng, 60, 500, 3000, foreign=0.002)
+    assert s.n_pos > 5 * 16384
+    T, P = make_library(rng, 14, 11)
+    if kind == "seq":
+        P = None
+    if kind == "struct":
+        T = None
+    lib = ctx.library(T, P)
+    thr_s = 3.0 if T is not None else None
+    thr_t = -6.0 if P is not None else None
+    want = ctx.library_hits_host(lib, s.codes if T is not None else None, s.profile if P is not None else None, thr_s, thr_t)
+    assert len(want[0]) > 200
+    for chunk in (1, 16384, 40000, 1 << 24):
+        got = ctx.library_hits_pipeline_host(lib, s.codes if T is not None else None, s.profile if P is not None else None, thr_s, thr_t,
+                                             chunk_positions=chunk)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        if T is not None:
+            assert_f32_bits_equal(got[2], want[2])
+        if P is not None:
+            assert np.array_equal(got[3].view(np.uint64), want[3].view(np.uint64))
+    with pytest.raises(ValueError):
+        ctx.scan_staged(ctx.motif(np.full((3, 8), np.nan)))            # nothing stays staged
+    lib.close()

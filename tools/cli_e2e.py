@@ -70,7 +70,7 @@ if RBIG:
     runs += [("big: seq only -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", big]),
              ("big: seq only -m 2", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", "-m", "2", big])]
 if RBIG and BIGSTORE:
-    for thr in ("0", " -4"):
+    for thr in ("0", " -4", " -9", " -12", " -14", " -16"):
         runs.append(("big: seq + struct (store) -m%s" % thr,
                      ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-q",
                       os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", thr,
