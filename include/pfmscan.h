@@ -384,6 +384,14 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                        int64_t *pieces /* [2 * PFMSCAN_TSV_MAX_PIECES] */, int *n_pieces,
                        int n_threads);
 
+/* Match_ID for rows that were formatted without it (rnascan/rnascan.py:329-332 numbers the rows 1..n AFTER every worker's
+ * table has been concatenated; here the ranks of a multi-GPU run format their own rows, and rank 0 numbers them while it
+ * relays them in rank order): copies `in` to `out` with "\t<id>" inserted in front of every line end that is not inside a
+ * double-quoted field, ids counting up from first_id.  *in_quotes carries the quote state from one block of a stream to the
+ * next (0 at the start).  capacity >= n + 21 x (line ends in the block) always suffices; PFMSCAN_E_CAPACITY otherwise. */
+int pfmscan_tsv_number(const char *in, int64_t n, int64_t first_id, char *out, int64_t capacity,
+                       int64_t *n_out, int64_t *n_rows, int *in_quotes);
+
 /* ---- measurement helper ------------------------------------------------------
  * Average device time in milliseconds of `iters` back-to-back pfmscan_scan_dev
  * launches, bracketed by hipEvents on the launch stream (after `warmup`

@@ -34,7 +34,7 @@ SYMBOLS = [
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
     "pfmscan_debug_quad_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
-    "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse",
+    "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -130,6 +130,7 @@ def load():
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
     L.pfmscan_profile_parse.argtypes = [ctypes.c_char_p, i64, i32, i64, vp, ctypes.POINTER(i64)]
+    L.pfmscan_tsv_number.argtypes = [vp, i64, i64, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i32), i32]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
@@ -250,6 +251,21 @@ def profile_parse(data, n_cols):
 
 
 TSV_MAX_PIECES = 16
+
+
+def tsv_number(block, first_id, in_quotes=0):
+    """rows formatted WITHOUT their Match_ID column (bytes) -> (the rows with it, number of rows, quote state at the end of
+    the block): "\\t<id>" in front of every line end outside a quoted field, ids counting up from ``first_id``"""
+    L = load()
+    src = np.frombuffer(block, dtype=np.uint8) if len(block) else np.zeros(1, dtype=np.uint8)
+    n = len(block)
+    cap = n + 21 * (block.count(b"\n") + 1) + 32
+    out = np.empty(cap, dtype=np.uint8)
+    n_out, n_rows, q = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(int(in_quotes))
+    rc = L.pfmscan_tsv_number(_ptr(src), n, int(first_id), _ptr(out), cap, ctypes.byref(n_out), ctypes.byref(n_rows), ctypes.byref(q))
+    if rc != OK:
+        _raise(L, None, rc)
+    return out[:n_out.value].tobytes(), int(n_rows.value), int(q.value)
 
 
 def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None, scratch=None):

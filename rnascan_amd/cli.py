@@ -137,7 +137,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
     and a ``sink`` the batches' tables go to ``sink(frame)`` one by one and None is returned."""
     rank, world, dist = dist_ctx
     ptype = np.dtype(args.profile_dtype).type
-    compact = sink is not None and world == 1            # streaming: hit columns go to the native writer as they are
+    compact = sink is not None                           # streaming: hit columns go to the native writer as they are
     if isinstance(source, fasta.Record):
         df = scanner.scan_records(engine, [source], pssm, letters, args.minscore)
         df["Sequence_ID"] = "testseq"
@@ -277,10 +277,18 @@ def main(argv=None, engine=None, out=None):
     final = None
     # One rank and one table (no join): every batch is written as soon as it is scanned -- same bytes,
     # Match_ID numbered across batches (rnascan.py:329-332) -- and never held as a whole.
+    # Several ranks: rank 0 streams its own rows the same way; every other rank streams its rows, formatted but
+    # without Match_ID, into a spool file that rank 0 appends in rank order, numbering as it copies (shard.relay_spools)
+    # -- no rank holds a table, the reference's pd.concat of every worker's frames (rnascan.py:407-408) never happens.
     writer = [None]
+    spool = [None, None]                                 # (text stream, path) of a rank > 0
 
     def stream_to(columns):
-        writer[0] = table.TsvWriter(out, columns, match_id=True)
+        if rank == 0:
+            writer[0] = table.TsvWriter(out, columns, match_id=True)
+        else:
+            spool[0], spool[1] = shard.open_spool()
+            writer[0] = table.TsvWriter(spool[0], columns, match_id=False, header=False)
 
         def sink(frame):
             if isinstance(frame, dict):                  # compact hit columns (table.py)
@@ -289,7 +297,7 @@ def main(argv=None, engine=None, out=None):
                 writer[0].write_chunk({c: frame[c].to_numpy() for c in writer[0].columns}, len(frame))
         return sink
 
-    streaming = world == 1 and not args.testseq
+    streaming = not args.testseq
     if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
         # sequence FASTA + averaged-structure directory (or packed store): one fused kernel pass per batch (configs 3, 5).
         # Only an index of both sides is held; a batch reads its own records and the profiles of those records.
@@ -396,6 +404,10 @@ def main(argv=None, engine=None, out=None):
 
     if writer[0] is not None:
         writer[0].close()                        # the last chunk may still be on the writer thread
+        if world > 1:
+            if spool[0] is not None:
+                spool[0].close()
+            shard.relay_spools(out, writer[0].rows + 1, spool[1], writer[0].rows if rank else 0, rank, world, dist)
     if rank == 0 and writer[0] is None:
         # Match_ID 1..n after all filtering / joining (rnascan.py:329-332), then the same bytes as
         # DataFrame.to_csv(sep='\t', index=False) (:559-567), written chunk by chunk

@@ -455,6 +455,43 @@ extern "C" int pfmscan_profile_parse(const char *buf, int64_t n, int n_cols, int
 
 extern "C" {
 
+// rows without their last column -> rows with it: "\t<id>" in front of every line end that is not inside a quoted field
+int pfmscan_tsv_number(const char *in, int64_t n, int64_t first_id, char *out, int64_t capacity, int64_t *n_out, int64_t *n_rows,
+                       int *in_quotes)
+{
+    if (!in || !out || !n_out || !n_rows || !in_quotes || n < 0 || capacity < 0 || first_id < 0)
+        return fail(nullptr, PFMSCAN_E_BADARG, "tsv_number: bad argument");
+    int q = *in_quotes ? 1 : 0;
+    int64_t rows = 0;
+    char *p = out, *const end = out + capacity;
+    const char *s = in, *const stop = in + n;
+    while (s < stop) {
+        // everything up to the next quote or line end is copied as it is
+        const char *e = s;
+        while (e < stop && *e != '\n' && *e != '"') ++e;
+        if (end - p < (e - s) + 24) return fail(nullptr, PFMSCAN_E_CAPACITY, "tsv_number: output buffer too small");
+        std::memcpy(p, s, (size_t)(e - s));
+        p += e - s;
+        if (e == stop) break;
+        if (*e == '"') {
+            q ^= 1;                                                  // a doubled quote toggles twice
+            *p++ = '"';
+        } else if (q) {
+            *p++ = '\n';                                             // a line break inside a quoted field
+        } else {
+            *p++ = '\t';
+            p = put_int(p, first_id + rows);
+            *p++ = '\n';
+            ++rows;
+        }
+        s = e + 1;
+    }
+    *in_quotes = q;
+    *n_out = p - out;
+    *n_rows = rows;
+    return PFMSCAN_OK;
+}
+
 int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_rows, int64_t first_match_id, char *out,
                        int64_t capacity, int64_t *need, int64_t *pieces, int *n_pieces, int n_threads)
 {

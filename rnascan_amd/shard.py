@@ -86,14 +86,15 @@ def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None, max_
     """Run ``scan_fn`` over this rank's contiguous range -- one call per batch of at
     most ``max_positions`` stream positions -- and gather the tables on rank 0.
     ``items`` is any sliceable list (records, profiles or pairs of them), ``lengths``
-    their lengths.  With one rank and a ``sink`` every batch's table is handed to
-    ``sink(frame)`` as soon as it exists and nothing is kept (returns None): the hit
-    table never has to fit in memory."""
+    their lengths.  With a ``sink`` every batch's table is handed to ``sink(frame)`` as soon
+    as it exists and nothing is kept or gathered (returns None on every rank): the hit table
+    never has to fit in memory -- a multi-rank caller gives every rank its own sink and joins the
+    ranks' outputs itself (``relay_spools``)."""
     if rank is None or world is None:
         rank, world = env_rank_world()
     lo, hi = partition(lengths, world)[rank]
     parts = batches(lengths, lo, hi, max_positions or batch_positions())
-    if sink is not None and world == 1:
+    if sink is not None:
         for a, b in parts:
             sink(scan_fn(items[a:b]))
         return None
@@ -104,3 +105,85 @@ def scan_sharded(items, lengths, scan_fn, rank=None, world=None, dist=None, max_
         full = [f for f in frames if f is not None and len(f)]
         local = pd.concat(full, ignore_index=True) if full else frames[0]
     return gather_frames(local, rank, world, dist)
+
+
+# ---------------------------------------------------------------------------
+# multi-rank output without a table in memory anywhere
+# ---------------------------------------------------------------------------
+SPOOL_BLOCK = 32 << 20
+
+
+def open_spool():
+    """a rank's row spool: a temporary file (RNASCAN_SPOOL_DIR, else the system's) that rank 0 reads back; text mode over
+    a byte stream, like stdout, so that the TSV writer takes its zero-copy path"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="rnascan_rows_", suffix=".tsv", dir=os.environ.get("RNASCAN_SPOOL_DIR") or None)
+    return os.fdopen(fd, "w", encoding="utf-8", newline=""), path
+
+
+def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
+    """Every rank > 0 has written its rows -- formatted, WITHOUT the Match_ID column -- to its spool file.  Rank 0 appends
+    them to ``out`` in rank order (= record order: the ranges are contiguous) and numbers them while it copies
+    (pfmscan_tsv_number), so that ``Match_ID`` is 1..n over the whole table as rnascan.py:329-332 makes it -- and no rank
+    ever holds more than one batch of rows.  The ranks of one node share a filesystem; a spool rank 0 cannot open is sent
+    over the process group in blocks instead.  Returns the next free id on rank 0 (None elsewhere)."""
+    import torch
+    from . import _lib
+    infos = [None] * world if rank == 0 else None
+    dist.gather_object((my_path, int(my_rows)), infos, dst=0)
+    readable = [None]
+    if rank == 0:
+        readable[0] = [r == 0 or infos[r][1] == 0 or os.access(infos[r][0], os.R_OK) for r in range(world)]
+    dist.broadcast_object_list(readable, src=0)
+    readable = readable[0]
+    if rank != 0:
+        if my_rows and not readable[rank]:
+            with open(my_path, "rb") as f:
+                while True:
+                    block = f.read(SPOOL_BLOCK)
+                    dist.send(torch.tensor([len(block)], dtype=torch.int64), dst=0)
+                    if not block:
+                        break
+                    dist.send(torch.frombuffer(bytearray(block), dtype=torch.uint8), dst=0)
+        dist.barrier()                                     # rank 0 is done with the file
+        if my_path and os.path.exists(my_path):
+            os.unlink(my_path)
+        return None
+    raw = getattr(out, "buffer", None)
+    if raw is not None:
+        out.flush()
+    next_id = int(first_id)
+
+    def emit(block, state):
+        nonlocal next_id
+        data, rows, state = _lib.tsv_number(block, next_id, state)
+        next_id += rows
+        if raw is not None:
+            raw.write(data)
+        else:
+            out.write(data.decode("utf-8"))
+        return state
+
+    for r in range(1, world):
+        path, rows = infos[r]
+        if not rows:
+            continue
+        state = 0
+        if readable[r]:
+            with open(path, "rb") as f:
+                while True:
+                    block = f.read(SPOOL_BLOCK)
+                    if not block:
+                        break
+                    state = emit(block, state)
+        else:
+            size = torch.zeros(1, dtype=torch.int64)
+            while True:
+                dist.recv(size, src=r)
+                if int(size[0]) == 0:
+                    break
+                buf = torch.empty(int(size[0]), dtype=torch.uint8)
+                dist.recv(buf, src=r)
+                state = emit(buf.numpy().tobytes(), state)
+    dist.barrier()
+    return next_id

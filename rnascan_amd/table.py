@@ -185,7 +185,7 @@ class TsvWriter(object):
     MAX_ROWS = 1 << 22                          # rows per native call (~0.5 GB of row buffer at the widest tables)
     ASYNC_ROWS = 1 << 18                        # chunks of at least this many rows are written out beside the next one's formatting
 
-    def __init__(self, out, columns, match_id=True):
+    def __init__(self, out, columns, match_id=True, header=True):
         self.out = out
         self.columns = list(columns)
         self.match_id = match_id
@@ -196,7 +196,8 @@ class TsvWriter(object):
         self._busy = [None, None]                # the write still reading each buffer
         self._turn = 0
         self._pool = None
-        out.write("\t".join([_quote(c) for c in self.columns] + (["Match_ID"] if match_id else [])) + "\n")
+        if header:
+            out.write("\t".join([_quote(c) for c in self.columns] + (["Match_ID"] if match_id else [])) + "\n")
 
     def write_chunk(self, data, n=None):
         if n is None:

@@ -223,3 +223,54 @@ def test_rnass_batches_equal_the_reference_join(tmp_path):
     scanner._add_match_id(want)
     assert got.getvalue() == want.to_csv(sep="\t", index=False)
     assert len(want) > 30
+
+
+def _cli_worker_no_gather(rank, world, port, outdir, argv):
+    """like _cli_worker, but any attempt to gather tables (pickled DataFrames through gather_object) fails the rank"""
+    sys.path.insert(0, REPO)
+    from rnascan_amd import shard
+
+    def boom(*a, **k):
+        raise AssertionError("a rank tried to gather whole tables")
+    shard.gather_frames = boom
+    _cli_worker(rank, world, port, outdir, argv)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_stream_their_rows_and_rank0_never_holds_a_table(tmp_path, monkeypatch):
+    """-m ' -inf' (every window a row) under two ranks: each rank streams its batches through the native row formatter;
+    rank 1's rows reach rank 0 as BYTES (spool file), rank 0 numbers Match_ID while it copies -- no gather of tables, and
+    the bytes equal the single-rank output.  Headers with tabs and quotes go through too (csv quoting survives the relay)."""
+    import io
+    import torch.multiprocessing as mp
+    from engines import OracleEngine
+    from rnascan_amd import cli
+    rng = np.random.default_rng(11)
+    fa = tmp_path / "all.fa"
+    with open(fa, "w") as f:
+        for i in range(31):
+            extra = ' with a "quote" and a\ttab' if i % 5 == 0 else ""
+            f.write(">rec%d desc %d%s\n%s\n" % (i, i, extra, "".join(rng.choice(list("ACGT"), size=int(rng.integers(20, 300))))))
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "100")     # several batches per rank (the RNA path takes 8 x this)
+    monkeypatch.setenv("RNASCAN_SPOOL_DIR", str(tmp_path))
+    argv = ["-p", os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-m", " -inf", str(fa)]
+    single = io.StringIO()
+    cli.main(argv, engine=OracleEngine(), out=single)
+    assert single.getvalue().count("\n") > 2000
+    mp.spawn(_cli_worker_no_gather, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
+    assert open(tmp_path / "out.1.tsv").read() == ""
+    assert not [p for p in os.listdir(tmp_path) if p.startswith("rnascan_rows_")]        # the spools are gone
+
+
+def test_tsv_number_respects_quoted_line_breaks_across_blocks():
+    from rnascan_amd import _lib
+    text = b'a\t1\n"x ""q""\ny"\t2\nlast\t3\n'
+    want = b'a\t1\t7\n"x ""q""\ny"\t2\t8\nlast\t3\t9\n'
+    got, rows, state = _lib.tsv_number(text, 7)
+    assert (got, rows, state) == (want, 3, 0)
+    for cut in range(1, len(text)):                        # any split into two blocks gives the same bytes
+        a, ra, st = _lib.tsv_number(text[:cut], 7)
+        b, rb, st = _lib.tsv_number(text[cut:], 7 + ra, st)
+        assert a + b == want and ra + rb == 3 and st == 0
+    assert _lib.tsv_number(b"", 1) == (b"", 0, 0)
