@@ -133,7 +133,8 @@ def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
     dist.gather_object((my_path, int(my_rows)), infos, dst=0)
     readable = [None]
     if rank == 0:
-        readable[0] = [r == 0 or infos[r][1] == 0 or os.access(infos[r][0], os.R_OK) for r in range(world)]
+        shared = os.environ.get("RNASCAN_SPOOL_SEND") != "1"       # "1": never read another rank's file (tests the send path)
+        readable[0] = [r == 0 or infos[r][1] == 0 or (shared and os.access(infos[r][0], os.R_OK)) for r in range(world)]
     dist.broadcast_object_list(readable, src=0)
     readable = readable[0]
     if rank != 0:

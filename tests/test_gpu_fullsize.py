@@ -227,6 +227,48 @@ def test_fullsize_c5_library_equals_all_scores(big, oracle):
     lib.close()
 
 
+def test_fullsize_struct_only_library_equals_all_scores(big):
+    """the structure side of BASELINE configs[4] alone at full size: 64 structure PFMs over the 100k x 3 kb profile in ONE
+    pass of k_profile_lib (every fourth motif with -inf cells: both forms of the kernel).  For motifs of every group
+    the library's hits are exactly the windows the single-motif all-scores kernel puts above the threshold, with
+    bit-identical scores; the per-motif counts add up to the total"""
+    import bench
+    torch = big["torch"]
+    from rnascan_amd import _lib
+    ctx, profile, n_pos, dev = big["ctx"], big["profile"], big["n_pos"], big["dev"]
+    n = 64
+    P = np.stack([bench.make_pssms(M, "inf" if k % 4 == 3 else "finite", seed=1000 + k)[1] for k in range(n)])
+    lib = ctx.library(None, P)
+    thr = np.where(np.arange(n) % 4 == 3, 0.5, 2.5)
+    cap = 1 << 26
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hm = torch.empty(cap, dtype=torch.int32, device=dev)
+    ht = torch.empty(cap, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.library_hits_dev(lib, None, profile.data_ptr(), _lib.PROFILE_F32, n_pos, None, thr, cap, hp.data_ptr(), hm.data_ptr(), None,
+                         ht.data_ptr(), cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    assert 10000 < k <= cap
+    per_motif = torch.bincount(hm[:k].long(), minlength=n)
+    out_st = torch.empty(n_pos, dtype=torch.float64, device=dev)
+    for mk in (0, 1, 2, 3, 31, 62, 63):
+        motif = ctx.motif(None, P[mk])
+        ctx.scan_dev(motif, None, profile.data_ptr(), _lib.PROFILE_F32, n_pos, None, out_st.data_ptr())
+        ctx.synchronize()
+        motif.close()
+        want = torch.nonzero(out_st > float(thr[mk])).flatten()
+        sel = torch.nonzero(hm[:k] == mk).flatten()
+        assert int(sel.numel()) == int(want.numel()) == int(per_motif[mk])
+        order = torch.argsort(hp[:k][sel])
+        idx = sel[order]
+        assert torch.equal(hp[:k][idx], want)
+        assert torch.equal(ht[:k][idx].view(torch.int64), out_st[want].view(torch.int64))       # bit-identical to k_profile
+    assert int(per_motif.sum()) == k
+    lib.close()
+
+
 def test_fullsize_c4_shard_of_125k_records(oracle):
     """one shard of BASELINE configs[3] (1M records over 8 GPUs = 125k x 3 kb per GPU, 375M positions): deterministic,
     NaN pattern, x2 exactness, hits == thresholded scores, 32 sampled records against the oracle"""

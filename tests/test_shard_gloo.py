@@ -257,10 +257,13 @@ def test_two_ranks_stream_their_rows_and_rank0_never_holds_a_table(tmp_path, mon
     single = io.StringIO()
     cli.main(argv, engine=OracleEngine(), out=single)
     assert single.getvalue().count("\n") > 2000
-    mp.spawn(_cli_worker_no_gather, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
-    assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
-    assert open(tmp_path / "out.1.tsv").read() == ""
-    assert not [p for p in os.listdir(tmp_path) if p.startswith("rnascan_rows_")]        # the spools are gone
+    for send in ("0", "1"):                                 # rank 0 reads the spool file / the rows travel over the process group
+        monkeypatch.setenv("RNASCAN_SPOOL_SEND", send)
+        mp.spawn(_cli_worker_no_gather, args=(3 if send == "1" else 2, _free_port(), str(tmp_path), argv), nprocs=3 if send == "1" else 2,
+                 join=True)
+        assert open(tmp_path / "out.0.tsv").read() == single.getvalue()
+        assert open(tmp_path / "out.1.tsv").read() == ""
+        assert not [p for p in os.listdir(tmp_path) if p.startswith("rnascan_rows_")]        # the spools are gone
 
 
 def test_tsv_number_respects_quoted_line_breaks_across_blocks():
