@@ -117,7 +117,7 @@ __device__ __forceinline__ void pl_score_motif(const double *tile, const double 
 #if defined(PL_ABLATE) && (PL_ABLATE & 1)                 // timing diagnostic builds only (tools/gpu_ab_c5s.sh): WRONG results
                 (void)prow;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) N[k] = C[k] * 1.0000001;
+                for (int k = 0; k < 7; ++k) N[k] = C[k];
 #else
 #pragma unroll
                 for (int k = 0; k < 7; ++k) N[k] = prow[k];
