@@ -459,7 +459,7 @@ extern "C" {
 int pfmscan_tsv_number(const char *in, int64_t n, int64_t first_id, char *out, int64_t capacity, int64_t *n_out, int64_t *n_rows,
                        int *in_quotes)
 {
-    if (!in || !out || !n_out || !n_rows || !in_quotes || n < 0 || capacity < 0 || first_id < 0)
+    if ((!in && n > 0) || (!out && capacity > 0) || !n_out || !n_rows || !in_quotes || n < 0 || capacity < 0 || first_id < 0)
         return fail(nullptr, PFMSCAN_E_BADARG, "tsv_number: bad argument");
     int q = *in_quotes ? 1 : 0;
     int64_t rows = 0;

@@ -1,6 +1,6 @@
 // ASan/UBSan fuzz driver for the host-only ingest code (CPU build, tests/test_ingest.py::test_ingest_under_sanitizers):
 // random FASTA-ish / profile-ish bytes in exact-size heap buffers through pfmscan_fasta_index / _ids / _encode,
-// pfmscan_gather_spans, pfmscan_tsv_format and pfmscan_profile_parse.  usage: fuzz_ingest [iterations]
+// pfmscan_gather_spans, pfmscan_tsv_format, pfmscan_tsv_number and pfmscan_profile_parse.  usage: fuzz_ingest [iterations]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +47,25 @@ int main(int argc, char **argv) {
             std::vector<char> out(need);
             rc = pfmscan_tsv_format(cols, 5, 50, 1, out.data(), need, &need, pieces, &np, threads);
             if (rc != 0) { printf("tsv rc %d\n", rc); return 1; }
+        }
+        // Match_ID splice over the same bytes (quotes, tabs and line ends at random places), in two blocks cut at a
+        // random point, into exact-size output buffers
+        {
+            const std::string t = s + "\"q\"\n";
+            std::vector<char> in(t.begin(), t.end());
+            const size_t cut = t.empty() ? 0 : rng() % (t.size() + 1);
+            int state = 0; int64_t nid = 1 + (int64_t)(rng() % 1000000007ull);
+            for (int part = 0; part < 2; ++part) {
+                const char *src = in.data() + (part ? cut : 0);
+                const int64_t len = part ? (int64_t)(t.size() - cut) : (int64_t)cut;
+                int64_t lines = 0; for (int64_t i = 0; i < len; ++i) lines += src[i] == '\n';
+                std::vector<char> exact_src(src, src + len);
+                std::vector<char> outb((size_t)(len + 21 * (lines + 1) + 32));
+                int64_t n_out = 0, n_rows = 0;
+                rc = pfmscan_tsv_number(exact_src.data(), len, nid, outb.data(), (int64_t)outb.size(), &n_out, &n_rows, &state);
+                if (rc != 0 || n_rows > lines || n_out < len) { printf("number rc %d\n", rc); return 1; }
+                nid += n_rows;
+            }
         }
         // profile-ish text
         std::vector<double> prof(7 * (n + 2)); int64_t rows = 0;
