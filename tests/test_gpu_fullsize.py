@@ -269,6 +269,45 @@ def test_fullsize_struct_only_library_equals_all_scores(big):
     lib.close()
 
 
+def test_engine_takes_the_library_pipeline_for_long_host_streams():
+    """a host-resident stream longer than 2 x 2^24 positions that only one library scans: HipEngine.library_hits goes
+    through pfmscan_library_hits_pipeline_host (three chunks here, upload beside scan) and returns what stage + scan returns"""
+    import torch
+    import bench
+    from rnascan_amd import pack, scanner
+    dev = torch.device("cuda", 0)
+    R2, L2 = 12500, 3000
+    codes, profile, n_pos = bench.make_stream(torch, dev, R2, L2, 99)
+    assert n_pos > scanner.PIPELINE_MIN
+    lengths = np.full(R2, L2, dtype=np.int64)
+    offsets = np.arange(R2, dtype=np.int64) * (L2 + 1)
+    stream = pack.Stream(codes.cpu().numpy(), profile.cpu().numpy(), offsets, lengths)
+    del codes, profile
+    tabs = [bench.make_pssms(M, "finite", seed=1000 + k) for k in range(24)]
+    T, P = np.stack([t for t, _ in tabs]), np.stack([p for _, p in tabs])
+    eng = scanner.HipEngine(0)
+    calls = []
+    real = eng.ctx.library_hits_pipeline_host
+    eng.ctx.library_hits_pipeline_host = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    got = eng.library_hits(stream, T, P, 6.0, -6.0)                       # one_shot: the pipeline
+    assert calls == [1]
+    want = eng.library_hits(stream, T, P, 6.0, -6.0, one_shot=False)      # staged once, scanned from the device
+    assert calls == [1]
+    assert len(want[0]) > 1000
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2].view(np.uint32), want[2].view(np.uint32))
+    assert np.array_equal(got[3].view(np.uint64), want[3].view(np.uint64))
+    # structure-only library over the same profile (a fresh Stream object: the one above is staged by now)
+    stream = pack.Stream(stream.codes, stream.profile, offsets, lengths)
+    got = eng.library_hits(stream, None, P, None, 2.0)
+    assert calls == [1, 1]
+    want = eng.library_hits(stream, None, P, None, 2.0, one_shot=False)
+    assert len(want[0]) > 1000
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[3].view(np.uint64), want[3].view(np.uint64))
+    eng.close()
+
+
 def test_fullsize_c4_shard_of_125k_records(oracle):
     """one shard of BASELINE configs[3] (1M records over 8 GPUs = 125k x 3 kb per GPU, 375M positions): deterministic,
     NaN pattern, x2 exactness, hits == thresholded scores, 32 sampled records against the oracle"""
