@@ -50,7 +50,10 @@ def spawn_ranks(world, cmd, capture_rank0=False, extra_env=None, poll=0.05, grac
             if rank == 0:
                 out = subprocess.PIPE if capture_rank0 else None
             else:
-                out = sys.stderr.fileno() if hasattr(sys.stderr, "fileno") else subprocess.DEVNULL
+                try:
+                    out = sys.stderr.fileno()
+                except (AttributeError, OSError, ValueError):      # a captured / replaced stderr without a descriptor
+                    out = subprocess.DEVNULL
             procs.append(subprocess.Popen(cmd, env=env, stdout=out))
         if capture_rank0:
             def pump():

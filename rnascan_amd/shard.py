@@ -154,6 +154,8 @@ def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
     if raw is not None:
         out.flush()
     next_id = int(first_id)
+    import codecs
+    text = codecs.getincrementaldecoder("utf-8")()         # a block may end inside a multi-byte character
 
     def emit(block, state):
         nonlocal next_id
@@ -162,7 +164,7 @@ def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
         if raw is not None:
             raw.write(data)
         else:
-            out.write(data.decode("utf-8"))
+            out.write(text.decode(data))
         return state
 
     for r in range(1, world):

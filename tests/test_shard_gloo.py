@@ -277,3 +277,31 @@ def test_tsv_number_respects_quoted_line_breaks_across_blocks():
         b, rb, st = _lib.tsv_number(text[cut:], 7 + ra, st)
         assert a + b == want and ra + rb == 3 and st == 0
     assert _lib.tsv_number(b"", 1) == (b"", 0, 0)
+
+
+def test_relay_into_a_text_sink_survives_blocks_that_split_a_character(tmp_path, monkeypatch):
+    """rank 0's side of relay_spools with a text sink without .buffer: the spool is read in blocks that end inside
+    multi-byte characters; the table comes out intact and numbered"""
+    import io
+    from rnascan_amd import shard
+    rows = ["récord %d ☃ désc\t%d" % (i, i) for i in range(40)]
+    spool = tmp_path / "rank1.tsv"
+    spool.write_bytes("".join(r + "\n" for r in rows).encode("utf-8"))
+
+    class OneNode(object):                                  # the collectives of a 2-rank group as rank 0 sees them
+        @staticmethod
+        def gather_object(obj, bucket, dst=0):
+            bucket[0], bucket[1] = obj, (str(spool), len(rows))
+
+        @staticmethod
+        def broadcast_object_list(box, src=0):
+            pass
+
+        @staticmethod
+        def barrier():
+            pass
+    monkeypatch.setattr(shard, "SPOOL_BLOCK", 7)
+    out = io.StringIO()
+    nxt = shard.relay_spools(out, 5, None, 0, 0, 2, OneNode)
+    assert nxt == 45
+    assert out.getvalue() == "".join("%s\t%d\n" % (r, 5 + i) for i, r in enumerate(rows))
