@@ -45,6 +45,15 @@ constexpr int PL_V = PL_V_OVERRIDE;                   // windows per thread
 constexpr int PL_NS = PL_V + 1;                       // row slots in registers: V in use + the one being filled for the next step
 constexpr int PL_UNROLL = (PL_NS % 2) ? 2 * PL_NS : PL_NS;   // steps per loop iteration: slot and row buffer are compile-time
 constexpr int PL_TILE = PL_LANES * PL_V;
+#ifndef PL_WAIT_FIRST
+#define PL_WAIT_FIRST 1
+#endif
+#ifndef PL_STAGGER
+#define PL_STAGGER 0                                  // x 64 cycles
+#endif
+#ifndef PL_INTERLEAVE
+#define PL_INTERLEAVE 0
+#endif
 constexpr int PL_QCAP = 128;                          // hits a wave can park (flushes before a 64-lane push could overflow)
 
 typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
@@ -99,56 +108,73 @@ __device__ __forceinline__ void pl_score_motif(const double *tile, const double 
         for (int k = 0; k < 7; ++k) rows[s][k] = vt[(la + s) * 7 + k];
         acc[s] = 0.0;
     }
+#if defined(PL_ABLATE) && (PL_ABLATE & 2)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) rows[V][k] = rows[0][k];
+#endif
     // Two PSSM row buffers, P (even steps) and Q (odd steps): step j requests row j + 1 into the OTHER buffer before its own
     // FMAs, so the wait for that row is at the top of step j + 1, a whole step later, and no copy sits in between (a
     // copy at the end of the step put the wait there, 28 FMAs after the request).
     double Q[7];
-#pragma unroll 1
-    for (int j0 = 0; j0 < m; j0 += PL_UNROLL) {
-#pragma unroll
-        for (int uu = 0; uu < PL_UNROLL; ++uu) {
-            const int j = j0 + uu;
-            if (j < m) {                              // wave-uniform
-                const int u = uu % NS;                // register slot that holds stream position la + j
-                double (&C)[7] = (uu & 1) ? Q : P;    // row j
-                double (&N)[7] = (uu & 1) ? P : Q;    // row j + 1, or row 0 of the group's next motif
-                const double *nrow = (j + 1 < m) ? pssm + (j + 1) * 7 : pssm_next;
-                const __attribute__((address_space(4))) double *prow = (const __attribute__((address_space(4))) double *)nrow;
+    // one step: `uu` (compile-time after unrolling) picks the register slot and the row buffer, `j` is the PSSM row
+    auto step = [&](const int uu, const int j) __attribute__((always_inline)) {
+        const int u = uu % NS;                        // register slot that holds stream position la + j
+        double (&C)[7] = (uu & 1) ? Q : P;            // row j
+        double (&N)[7] = (uu & 1) ? P : Q;            // row j + 1, or row 0 of the group's next motif
+#if PL_WAIT_FIRST
+        // wait for the row requested a step ago BEFORE requesting the next one: scalar loads return out of order, so
+        // the wait in front of this step's first FMA is lgkmcnt(0) -- left to the scheduler, the new requests were
+        // hoisted above it in every other step and the wave sat out a full L2 round trip there
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const double *nrow = (j + 1 < m) ? pssm + (j + 1) * 7 : pssm_next;
+        const __attribute__((address_space(4))) double *prow = (const __attribute__((address_space(4))) double *)nrow;
 #if defined(PL_ABLATE) && (PL_ABLATE & 1)                 // timing diagnostic builds only (tools/gpu_ab_c5s.sh): WRONG results
-                (void)prow;
+        (void)prow;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) N[k] = C[k];
+        for (int k = 0; k < 7; ++k) N[k] = C[k];
 #else
 #pragma unroll
-                for (int k = 0; k < 7; ++k) N[k] = prow[k];
+        for (int k = 0; k < 7; ++k) N[k] = prow[k];
 #endif
-                // the free slot takes position la + j + V (always staged: the tile holds T + m rows)
+        // the free slot takes position la + j + V (always staged: the tile holds T + m rows)
 #if defined(PL_ABLATE) && (PL_ABLATE & 2)
-#pragma unroll
-                for (int k = 0; k < 7; ++k) rows[(u + V) % NS][k] = rows[u][k] + 1.0;
+        // the slot keeps its stale row: no LDS read and no instruction in its place
 #else
 #pragma unroll
-                for (int k = 0; k < 7; ++k) rows[(u + V) % NS][k] = vt[(la + j + V) * 7 + k];
+        for (int k = 0; k < 7; ++k) rows[(u + V) % NS][k] = vt[(la + j + V) * 7 + k];
 #endif
-                if (FINITE) {
-                    // same terms in the same order per window (bit-identical to k_profile's FINITE form)
+        if (FINITE) {
+            // same terms in the same order per window (bit-identical to k_profile's FINITE form)
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < 7; ++k) {
 #pragma unroll
-                        for (int v = 0; v < V; ++v) acc[v] = fma(rows[(u + v) % NS][k], C[k], acc[v]);
-                    }
-                } else {
+                for (int v = 0; v < V; ++v) acc[v] = fma(rows[(u + v) % NS][k], C[k], acc[v]);
+            }
+        } else {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const int slot = (u + v) % NS; // holds stream position la + v + j
-                        double d = rows[slot][0] * C[0];
+            for (int v = 0; v < V; ++v) {
+                const int slot = (u + v) % NS;        // holds stream position la + v + j
+                double d = rows[slot][0] * C[0];
 #pragma unroll
-                        for (int k = 1; k < 7; ++k) d = fma(rows[slot][k], C[k], d);
-                        acc[v] += pl_nan_to_num(d);
-                    }
-                }
+                for (int k = 1; k < 7; ++k) d = fma(rows[slot][k], C[k], d);
+                acc[v] += pl_nan_to_num(d);
             }
         }
+    };
+    // whole groups of PL_UNROLL steps run as ONE basic block (no test between the steps: a taken branch per 35 FMAs costs
+    // the wave ~30 cycles of refetch); the last m mod PL_UNROLL steps are tested one by one.  PL_UNROLL is even and a
+    // multiple of NS, so slot and row-buffer parity carry over from group to group.
+    int j0 = 0;
+#pragma unroll 1
+    for (; j0 + PL_UNROLL <= m; j0 += PL_UNROLL) {
+#pragma unroll
+        for (int uu = 0; uu < PL_UNROLL; ++uu) step(uu, j0 + uu);
+    }
+#pragma unroll
+    for (int uu = 0; uu < PL_UNROLL - 1; ++uu) {
+        if (j0 + uu < m) step(uu, j0 + uu);           // wave-uniform
     }
     if (m & 1) {                                       // an odd number of steps leaves the next motif's row 0 in Q
 #pragma unroll
@@ -197,7 +223,17 @@ __global__ __launch_bounds__(PL_BLOCK) void k_profile_lib(const ProfLibArgs a)
             for (int e = 0; e < PER; e += 2) *reinterpret_cast<pl_f64x2 *>(tile + i + e) = pl_f64x2{d[e], d[e + 1]};
         }
     }
+    if (threadIdx.x < PL_LANES / 64)                   // motif tickets, one per window range: the first PL_GROUPS motifs are fixed
+        reinterpret_cast<uint32_t *>(smem + pl_tile_bytes(m) + pl_queue_bytes())[threadIdx.x] = PL_GROUPS;
     __syncthreads();                                   // the only workgroup barrier: the waves are independent from here on
+#if PL_STAGGER
+    // the four waves of a SIMD (one per motif group) run the same instruction stream and are issued round-robin: left in
+    // phase they reach the branch and the wait at the end of every step TOGETHER and the FMA pipe idles through it.  A
+    // quarter step of head start each keeps one wave's bubble under the other three's FMAs.
+    if (group == 1) __builtin_amdgcn_s_sleep(PL_STAGGER);
+    if (group == 2) __builtin_amdgcn_s_sleep(2 * PL_STAGGER);
+    if (group == 3) __builtin_amdgcn_s_sleep(3 * PL_STAGGER);
+#endif
 
     const int shard = blockIdx.x & (a.hit_shards - 1);
     unsigned long long *counter = a.hit_count + (size_t)shard * HIT_COUNTER_STRIDE;
@@ -228,32 +264,54 @@ __global__ __launch_bounds__(PL_BLOCK) void k_profile_lib(const ProfLibArgs a)
     const int la = (threadIdx.x & (PL_LANES - 1)) * V;
     // windows this lane may report: they start inside the stream and their m rows end inside it (a window that runs over
     // the end has no score: NaN in the all-scores kernels)
-    bool live[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) live[v] = tile0 + la + v + m <= n_pos;
+    // (one wave-uniform count, compared at the end of each motif: five lane masks held across the motif loop cost ten SGPRs)
+    const int64_t live_all = n_pos - m + 1 - tile0;
+    const int live_n = live_all < 0 ? 0 : (live_all > PL_TILE ? PL_TILE : (int)live_all);
     const __attribute__((address_space(4))) double *thr = (const __attribute__((address_space(4))) double *)a.thr;
     const __attribute__((address_space(4))) int32_t *finite = (const __attribute__((address_space(4))) int32_t *)a.finite;
 
+    // Which motif a wave scores next is decided at run time.  The four waves that share a window range (one per motif
+    // group) sit on ONE SIMD, and its arbiter favours the oldest wave: with a fixed quarter of the library each, the
+    // favoured wave was done at ~70 % of the workgroup's time and its slot stayed empty until the last one ended (a
+    // 1024-thread workgroup frees its CU as a whole) -- 28 % of the wave slots idle in the counters.  The waves of a range
+    // take motifs from a shared LDS ticket instead: they end within one motif of each other.  A wave knows its next motif
+    // one motif ahead (the PSSM row prefetch needs it); the ticket for the one after is drawn between two motifs (one LDS
+    // round trip per motif and wave, under the other waves' FMAs).
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(smem + pl_tile_bytes(m) + pl_queue_bytes()) + (wave & (PL_LANES / 64 - 1));
+    auto draw = [&]() -> uint32_t {                    // lane 0's VGPR holds the ticket once the LDS atomic has returned
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(ticket, 1u);
+        return v;
+    };
+    const int nm = a.n_motifs;
+    int k = group;                                     // the first motif of every wave is fixed
+    int kn = nm;
     double P[7];                                       // PSSM row in use (SGPRs); pl_score_motif leaves the next motif's row 0 in it
-    if (group < a.n_motifs) {
-        const __attribute__((address_space(4))) double *p0 = (const __attribute__((address_space(4))) double *)(a.pssm + (size_t)group * m * 7);
+    int fin = 0;
+    if (k < nm) {
+        const __attribute__((address_space(4))) double *p0 = (const __attribute__((address_space(4))) double *)(a.pssm + (size_t)k * m * 7);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) P[k] = p0[k];
+        for (int c = 0; c < 7; ++c) P[c] = p0[c];
+        fin = finite[k];
+        kn = (int)__builtin_amdgcn_readfirstlane(draw());
     }
 #pragma unroll 1
-    for (int k = group; k < a.n_motifs; k += PL_GROUPS) {
+    while (k < nm) {
         const double *pssm = a.pssm + (size_t)k * m * 7;
-        const int kn = k + PL_GROUPS < a.n_motifs ? k + PL_GROUPS : k;      // after the group's last motif: any valid row
-        const double *pssm_next = a.pssm + (size_t)kn * m * 7;
+        const int kc = kn < nm ? kn : k;               // after the wave's last motif: any valid row
+        const double *pssm_next = a.pssm + (size_t)kc * m * 7;
+        // this motif's threshold and the next motif's form are requested HERE, a whole motif before their use
+        const double t = thr[k];
+        const int fin_next = finite[kc];
         double acc[V];
-        if (finite[k])
+        if (fin)
             pl_score_motif<true>(tile, pssm, pssm_next, m, la, acc, P);
         else
             pl_score_motif<false>(tile, pssm, pssm_next, m, la, acc, P);
-        const double t = thr[k];
+        fin = fin_next;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const bool pass = live[v] && (acc[v] > t);
+            const bool pass = (la + v < live_n) && (acc[v] > t);
             const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
             if (mk) {                                  // wave-uniform
                 if (qn + 64 > PL_QCAP) flush();
@@ -265,6 +323,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_profile_lib(const ProfLibArgs a)
                 qn += __popcll(mk);
             }
         }
+        k = kn;
+        if (kn < nm) kn = (int)__builtin_amdgcn_readfirstlane(draw());     // wave-uniform
     }
     if (qn > 0) flush();
 }
@@ -276,7 +336,7 @@ hipError_t launch_profile_library(const ProfLibArgs &a, hipStream_t stream)
     if (a.n_pos <= 0 || a.n_motifs <= 0) return hipSuccess;
     if (a.n_motifs > 65536 || a.m < 1 || a.m > PFMSCAN_MAX_M) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((a.n_pos + PL_TILE - 1) / PL_TILE);
-    const size_t lds = (size_t)pl_tile_bytes(a.m) + pl_queue_bytes();
+    const size_t lds = (size_t)pl_tile_bytes(a.m) + pl_queue_bytes() + 16;       // + the motif tickets
     static std::atomic<uint64_t> done_f{0}, done_d{0};
     if (a.profile_dtype == PFMSCAN_PROFILE_F64) {
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(k_profile_lib<double>), done_d, 160 * 1024);
