@@ -141,6 +141,7 @@ __host__ __device__ constexpr int lib_mpg(int np_bucket) { return np_bucket == 8
 __host__ __device__ constexpr int lib_credit_bits(int np_bucket) { return np_bucket == 8 ? 10 : 16; }
 constexpr int LIB_SHARDS = 256;           // sharded hit buffers of a library scan: workgroup b appends to shard b & 255
 
+constexpr int LIB_SEG_SHIFT = 14;           // windows per work segment of k_library: 16384 (the kernel turns chunk tickets into positions with shifts)
 struct LibArgs {
     const uint8_t *codes;                 // [n_pos]
     const void *profile;                  // [n_pos][7] or null (sequence-only library)
@@ -148,7 +149,7 @@ struct LibArgs {
     int64_t n_pos;                        // stream length (bounds of every read)
     int64_t pos_base, span;               // this launch scores the windows starting in [pos_base, pos_base + span), span < 2^32
     int64_t pos_offset;                   // added to every reported hit position (chunked host pipeline: where the buffer sits in the stream)
-    int64_t seg_positions, n_seg;         // work split: segment s (seg_positions windows, multiple of 1024) -> workgroup s mod grid
+    int64_t seg_positions, n_seg;         // work split: segment s (seg_positions = 2^LIB_SEG_SHIFT windows) -> workgroup s mod grid
     // one pass = nmp = 8 * ng motifs, tables laid out for the kernel (pfmscan_library_api.hip builds them)
     const uint32_t *pairs;                // [npair][ng][16][8] u16 two-letter credits, threshold folded into pair row 0
     const double *letters;                // [m * 4][nmp] fp64, transposed

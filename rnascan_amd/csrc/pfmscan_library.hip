@@ -311,8 +311,9 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 
     // ---- LDS carve-up (same arithmetic as lib_lds_bytes) ----
     const int pair_bytes = npair * NG * 256;        // + one all-zero row of NG * 256 bytes: row 0 of the windows that cannot score
-    uint32_t *pairs = reinterpret_cast<uint32_t *>(smem);
-    double *letters = reinterpret_cast<double *>(smem + pair_bytes + NG * 256);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(smem);          // the workgroup's chunk ticket (see the chunk loop): 16 bytes at a constant address
+    uint32_t *pairs = reinterpret_cast<uint32_t *>(smem + 16);
+    double *letters = reinterpret_cast<double *>(smem + 16 + pair_bytes + NG * 256);
     double *pssm = letters + (size_t)m * 4 * NMP;
     double *thr_s = pssm + (HAS_STRUCT ? (size_t)m * 8 * NMP : 0);
     double *thr_t = thr_s + NMP;
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         thr_s[i] = a.thr_seq[i];
         thr_t[i] = HAS_STRUCT ? a.thr_struct[i] : -INFINITY;
     }
+    if (threadIdx.x == 0) *ticket = LIB_WAVES;      // the first chunk of wave w is chunk w
     __syncthreads();                                // the only workgroup barrier: waves are independent from here on
 
     const int64_t n_pos = a.n_pos;
@@ -462,13 +464,28 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     };
 
     // ---- phase A: this workgroup's segments, this wave's 64-window chunks ----
+    // The workgroup's chunks -- the 64-window chunks of its segments blockIdx.x, blockIdx.x + gridDim.x, ... in order -- are
+    // handed out by an LDS ticket, not dealt round-robin: the SIMD arbiter favours the oldest wave, and with a fixed share
+    // each the favoured waves of this persistent workgroup were done at ~85 % of the kernel's time, their slots empty for
+    // the rest (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE in profiles/r3/bench_c5_pmc_summary.txt).  The ticket for the chunk
+    // after this one is drawn before the chunk and read after it.
     int qn = 0;                                     // wave-uniform queue length (< 64 between chunks)
-    const int chunks_per_seg = (int)(a.seg_positions >> 6);
-    for (int64_t seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
-        const int64_t seg0 = seg * a.seg_positions;          // relative to pos_base
-        for (int c = wave; c < chunks_per_seg; c += LIB_WAVES) {
-            const int64_t rel0 = seg0 + (int64_t)c * 64;
-            if (rel0 >= a.span) break;                       // wave-uniform
+    constexpr int seg_shift = LIB_SEG_SHIFT - 6;    // chunks per segment (launch_library insists on seg_positions == 2^LIB_SEG_SHIFT)
+    const int64_t my_segs = blockIdx.x < a.n_seg ? (a.n_seg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t n_units = (uint32_t)(my_segs << seg_shift);
+    constexpr bool AHEAD = NP <= 8;                 // the wider buckets have no VGPR to hold the ticket across a chunk
+    uint32_t drawn = 0;
+    auto next_unit = [&]() -> uint32_t {
+        if (!AHEAD && lane == 0) drawn = atomicAdd(ticket, 1u);
+        return __builtin_amdgcn_readfirstlane(drawn);
+    };
+    for (uint32_t u = (uint32_t)wave; u < n_units; u = next_unit()) {
+        if (AHEAD && lane == 0) drawn = atomicAdd(ticket, 1u);
+        {
+            // segment blockIdx.x + (u >> seg_shift) gridDim.x, chunk u mod 2^seg_shift of it; relative to pos_base
+            const int64_t rel0 = ((int64_t)(blockIdx.x + (u >> seg_shift) * gridDim.x) << (seg_shift + 6)) +
+                                 (int64_t)((u & ((1u << seg_shift) - 1u)) << 6);
+            if (rel0 >= a.span) continue;                    // wave-uniform (the last segment may run over the span)
             const int64_t p0 = a.pos_base + rel0;            // multiple of 64
             // the lane's letters: bytes [p0 + lane, p0 + lane + 2 NP) from NRAW aligned dwords
             const int64_t al = p0 + (lane & ~3);
@@ -548,7 +565,7 @@ size_t lib_group_bytes(int m, int npair, bool has_struct, int np_bucket)
     return (size_t)(npair + 1) * 256 + (size_t)lib_mpg(np_bucket) * ((size_t)m * 32 + (has_struct ? (size_t)m * 64 : 0) + 16);
 }
 
-size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * 3 * 4; }
+size_t lib_queue_bytes(int np_bucket) { return (size_t)(lib_block(np_bucket) / 64) * LIB_QCAP * 3 * 4 + 16; }     // + the chunk ticket
 
 size_t lib_lds_bytes(int m, int npair, int ng, bool has_struct, int np_bucket)
 {
@@ -600,7 +617,9 @@ hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream)
     if (a.span <= 0 || a.nmp <= 0) return hipSuccess;
     const int np = lib_np_bucket(a.m);
     const size_t lds = lib_lds_bytes(a.m, a.npair, a.ng, a.pssm != nullptr, np);
-    if (lds > 160 * 1024 || a.ng * lib_mpg(np) != a.nmp || (a.seg_positions & 1023)) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 || a.ng * lib_mpg(np) != a.nmp || a.seg_positions != ((int64_t)1 << LIB_SEG_SHIFT) ||
+        ((a.n_seg + n_cu - 1) / n_cu) * (a.seg_positions >> 6) > 0x7FFFFFFF)
+        return hipErrorInvalidValue;
     const unsigned grid = (unsigned)std::min<int64_t>(a.n_seg, n_cu);
 #define LIB_CASE(NGV, NPV) \
     if (np == NPV && a.ng == NGV) return launch_library_ng<NGV, NPV>(a, grid, lds, stream)

@@ -369,7 +369,7 @@ static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const doub
     return PFMSCAN_OK;
 }
 
-constexpr int64_t LIB_SEG = 16384;        // windows per work segment (segment s -> workgroup s mod grid, shard s mod 256)
+constexpr int64_t LIB_SEG = (int64_t)1 << LIB_SEG_SHIFT;        // windows per work segment (segment s -> workgroup s mod grid, shard s mod 256)
 
 struct LibSink {
     int64_t *pos;
