@@ -467,7 +467,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     // The workgroup's chunks -- the 64-window chunks of its segments blockIdx.x, blockIdx.x + gridDim.x, ... in order -- are
     // handed out by an LDS ticket, not dealt round-robin: the SIMD arbiter favours the oldest wave, and with a fixed share
     // each the favoured waves of this persistent workgroup were done at ~85 % of the kernel's time, their slots empty for
-    // the rest (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE in profiles/r3/bench_c5_pmc_summary.txt).  The ticket for the chunk
+    // the rest (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE in profiles/r3/bench_c5_pmc_summary_before_tickets.txt).  The ticket for the chunk
     // after this one is drawn before the chunk and read after it.
     int qn = 0;                                     // wave-uniform queue length (< 64 between chunks)
     constexpr int seg_shift = LIB_SEG_SHIFT - 6;    // chunks per segment (launch_library insists on seg_positions == 2^LIB_SEG_SHIFT)
