@@ -81,6 +81,7 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     if (!ctx) return fail(nullptr, PFMSCAN_E_OOM, "out of host memory");
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
+    ctx->tune.n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

@@ -66,6 +66,7 @@ struct Tuning {
     int ablate = 0;         // see ScanArgs::ablate; results are WRONG when non-zero
     int prefilter = 1;      // hits over 4-letter alphabets: fp32 two-letter prefilter, exact fp64 re-score of survivors
     int tiles_per_block = 0; // k_letters_pre: 0 = pick from the stream length; > 0 forces it (PFMSCAN_TILES_PER_BLOCK, tests)
+    int n_cu = 256;         // compute units of the ctx's device (set at ctx creation): sizes the grids of the tile-walking kernels
     int two_phase = 1;      // combined hits through the host/staged API: letters first, structure only at candidates
     int credits = 1;        // hits over 4-letter alphabets, m <= 32: integer position-keyed prefilter (k_letters_cred) instead of
                             // the fp32 one (k_letters_pre); PFMSCAN_CREDITS=0 for A/B runs and tests

@@ -1465,6 +1465,18 @@ static hipError_t allow_full_lds(const void *kern, std::atomic<uint64_t> &done)
 }
 
 // integer position-keyed prefilter (k_letters_cred) for a single 4-letter motif of width <= 32 with a finite threshold;
+// Tiles one workgroup of a tile-walking hits kernel (k_letters_pre / _cred / _quad) takes.  A workgroup pays its table load,
+// its final flush and its launch once, so more tiles per workgroup are cheaper -- until the grid is only a round or two of
+// the 5-6 workgroups a CU holds (26 KB of LDS each): 32 tiles on C2 = 2290 workgroups = 1.5 rounds of 1536, and the second
+// round ran on a half-empty chip (4.2 resident waves per SIMD on average in the counters).  ~24 workgroups per CU = four
+// or five rounds: C2 (w = 8) -m 6 0.134 -> 0.128 ms, no hits 0.084 -> 0.079, k_letters_pre 0.211 -> 0.191, w = 4 -m 2
+// 0.400 -> 0.355 (tools/gpu_sweep_tpb.sh).
+static int walk_tiles(int64_t ntiles, const Tuning &t)
+{
+    const int64_t per = (int64_t)t.n_cu * 24;
+    return (int)std::min<int64_t>(32, std::max<int64_t>(1, (ntiles + per / 2) / per));
+}
+
 // false when the motif has +inf / NaN two-letter sums (the fp32 prefilter handles those)
 static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
@@ -1512,7 +1524,7 @@ static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t 
         for (int tr = 0; tr < npair; ++tr) ct.d[i][tr >> 1] |= (uint32_t)cr[tr * 16 + i] << (16 * (tr & 1));
     ScanArgs b = a;
     const int64_t ntiles = (a.n_pos + CRED_TILE - 1) / CRED_TILE;
-    b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+    b.tiles_per_block = walk_tiles(ntiles, t);
     if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
     const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
     switch (nj) {
@@ -1555,7 +1567,7 @@ static bool launch_letters_quad(const ScanArgs &a, const Tuning &t, hipStream_t 
     }
     ScanArgs b = a;
     const int64_t ntiles = (a.n_pos + QUAD_TILE - 1) / QUAD_TILE;
-    b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+    b.tiles_per_block = walk_tiles(ntiles, t);
     if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
     const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
     switch (nq) {
@@ -1583,7 +1595,7 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
         // >= 2048 workgroups when the stream allows, at most 32 tiles per workgroup
         ScanArgs b = a;
         const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
-        b.tiles_per_block = (int)std::min<int64_t>(32, std::max<int64_t>(1, ntiles / 2048));
+        b.tiles_per_block = walk_tiles(ntiles, t);
         if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;      // tests: the multi-tile walk on small streams
         const double lo = a.thr_seq - a.pair_eps;
         b.thr_pre = (float)lo;
