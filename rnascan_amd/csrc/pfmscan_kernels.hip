@@ -360,10 +360,11 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
     constexpr int LET_TILE = let_tile(NDW);
     constexpr int NW = NDW + 1;                        // code dwords per round: bytes 0 .. W + m - 1 (+1 for the pair)
     constexpr int NWAVE = BLOCK / 64;
-    __shared__ __align__(16) double tbl[PFMSCAN_MAX_M * 8];
-    __shared__ __align__(16) float ptab[(PFMSCAN_MAX_M / 2) * 16];
+    constexpr int MAXM = (NDW - 1) * 4;                // widest PFM of this instantiation (the launcher picks NDW from m)
+    __shared__ __align__(16) double tbl[MAXM * 8];     // sized by the instantiation, not by PFMSCAN_MAX_M: m <= 16 fits 8 workgroups per CU
+    __shared__ __align__(16) float ptab[(MAXM / 2) * 16];
     __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
-    __shared__ int64_t q_pos[NWAVE][WQ_CAP];
+    __shared__ uint32_t q_pos[NWAVE][WQ_CAP];          // relative to the workgroup's first tile (4 bytes: 22.7 instead of 26.8 KB of LDS)
     __shared__ float q_sc[NWAVE][WQ_CAP];
     __shared__ int q_n[NWAVE], snap[2][NWAVE];
     __shared__ unsigned long long s_base;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
     const int shard = blockIdx.x & (a.hit_shards - 1);
     const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.capacity;
     unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
-    int64_t *my_pos = q_pos[wave];
+    uint32_t *my_pos = q_pos[wave];
     float *my_sc = q_sc[wave];
 
     auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i = lane; i < n; i += 64) store_hit(base + i, my_pos[i], my_sc[i]);
+        for (int i = lane; i < n; i += 64) store_hit(base + i, first + (int64_t)my_pos[i], my_sc[i]);
         if (lane == 0) q_n[wave] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
                         const float f = (float)sc;
                         if ((double)f > a.thr_seq) {
                             const int slot = atomicAdd(&q_n[wave], 1);     // LDS
-                            my_pos[slot] = tile0 + off0 + v;
+                            my_pos[slot] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
                             my_sc[slot] = f;
                         }
                     }
@@ -559,11 +560,12 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     __shared__ __align__(16) double tbl[TROWS * 8];
     __shared__ __align__(16) uint32_t ctab[16 << (ESH - 2)];
     __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
-    __shared__ int64_t q_pos[NWAVE][WQ_CAP];
+    __shared__ uint32_t q_pos[NWAVE][WQ_CAP];          // positions in both queues are relative to the workgroup's first tile:
     __shared__ float q_sc[NWAVE][WQ_CAP];
     __shared__ int q_n[NWAVE], snap[2][NWAVE];
     __shared__ unsigned long long s_base;
-    __shared__ int64_t sv_pos[NWAVE][128];             // survivors of the prefilter waiting for their exact score
+    __shared__ uint32_t sv_pos[NWAVE][128];            // 4-byte entries keep the workgroup under 20 KB of LDS = 8 per CU (26 KB: 6);
+                                                       // sv_pos: survivors of the prefilter waiting for their exact score
     const int m = a.m;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n_pos = a.n_pos;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     const int shard = blockIdx.x & (a.hit_shards - 1);
     const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.capacity;
     unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
-    int64_t *my_pos = q_pos[wave];
+    uint32_t *my_pos = q_pos[wave];
     float *my_sc = q_sc[wave];
 
     auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i = lane; i < n; i += 64) store_hit(base + i, my_pos[i], my_sc[i]);
+        for (int i = lane; i < n; i += 64) store_hit(base + i, first + (int64_t)my_pos[i], my_sc[i]);
         if (lane == 0) q_n[wave] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
 
     int qn_ub = 0;                                     // wave-uniform upper bound of q_n[wave]
     int sv_n = 0;                                      // wave-uniform length of the survivor queue (< 64 between windows)
-    int64_t *my_sv = sv_pos[wave];
+    uint32_t *my_sv = sv_pos[wave];
     // exact score of survivors [at, at + cnt) of this wave's queue, one per lane (_pwm.c:34-68)
     auto exact_batch = [&](int at, int cnt) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         }
         qn_ub += cnt;
         if (lane < cnt) {
-            const int64_t p = my_sv[at + lane];
+            const int64_t p = first + (int64_t)my_sv[at + lane];
             const int64_t al = p & ~(int64_t)3;
             uint32_t raw[NJ + 1];
 #pragma unroll
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
             const float f = (float)sc;
             if ((double)f > a.thr_seq) {
                 const int slot = atomicAdd(&q_n[wave], 1);     // LDS
-                my_pos[slot] = p;
+                my_pos[slot] = (uint32_t)(p - first);
                 my_sc[slot] = f;
             }
         }
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
                 const bool sv = (sum[v] & 0x8000u) != 0;
                 const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
                 if (sb) {                               // wave-uniform
-                    if (sv) my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = tile0 + off0 + v;
+                    if (sv) my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
                     sv_n += __popcll(sb);
                     if (sv_n >= 64) {                   // the top 64 get their exact score, the rest stays
                         exact_batch(sv_n - 64, 64);
