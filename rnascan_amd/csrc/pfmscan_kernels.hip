@@ -1374,6 +1374,40 @@ __device__ __forceinline__ double struct_score_at(const void *profile, int64_t p
     return score;
 }
 
+// The same score with the loads of ALL row groups issued before the first use (NG = ceil(m / 4) <= 4 groups, 7 vectors
+// each): one memory round trip per candidate instead of NG dependent ones.  Same rows, same operation order, same bits.
+template <typename PROF_T, int NG>
+__device__ __forceinline__ double struct_score_at_wide(const void *profile, int64_t p, int m, const double *struct_pssm)
+{
+    typedef PROF_T v4_t __attribute__((ext_vector_type(4), aligned(sizeof(PROF_T))));
+    const PROF_T *__restrict__ prof = reinterpret_cast<const PROF_T *>(profile) + p * 7;
+    const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)struct_pssm;
+    v4_t q[NG][7];
+    int base[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        base[g] = 4 * g < m - 4 ? 4 * g : m - 4;       // the last group is moved back to end with the window (m >= 4 here)
+        const PROF_T *r = prof + base[g] * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q[g][k] = *reinterpret_cast<const v4_t *>(r + 4 * k);
+    }
+    double score = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base[g] + u;
+            if (j >= 4 * g && j < m) {                  // rows a previous group already added are skipped
+                double d = (double)q[g][(u * 7) >> 2][(u * 7) & 3] * pssm[j * 7];
+#pragma unroll
+                for (int c = 1; c < 7; ++c) d = fma((double)q[g][(u * 7 + c) >> 2][(u * 7 + c) & 3], pssm[j * 7 + c], d);
+                score += nan_to_num(d);
+            }
+        }
+    }
+    return score;
+}
+
 // ---------------------------------------------------------------------------
 // k_struct_at -- verify phase of the candidate-then-verify combined scan.
 // A combined hit needs seq > thr AND struct > thr (rnascan.py:422-433 joins two
@@ -1426,7 +1460,11 @@ __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int
             const int64_t at = (int64_t)shard * cand_shard_cap + i;
             p = cand_pos[at];
             sq = cand_seq[at];
-            score = struct_score_at<PROF_T>(a.profile, p, m, a.struct_pssm);
+            // widths 5 .. 16: every row group in flight at once (wave-uniform choice; float rows: 84-112 VGPRs of loads)
+            if (sizeof(PROF_T) == 4 && m > 8 && m <= 12) score = struct_score_at_wide<PROF_T, 3>(a.profile, p, m, a.struct_pssm);
+            else if (sizeof(PROF_T) == 4 && m > 12 && m <= 16) score = struct_score_at_wide<PROF_T, 4>(a.profile, p, m, a.struct_pssm);
+            else if (sizeof(PROF_T) == 4 && m > 4 && m <= 8) score = struct_score_at_wide<PROF_T, 2>(a.profile, p, m, a.struct_pssm);
+            else score = struct_score_at<PROF_T>(a.profile, p, m, a.struct_pssm);
             mask = score > a.thr_struct ? 1u : 0u;
         }
         emit_hits_block<1>(mask, [&](int) { return p; }, [&](int) { return sq; }, [&](int) { return score; }, a);
