@@ -157,6 +157,14 @@ struct LibArgs {
     const double *pssm;                   // [m * 4][nmp][2] fp64: row j, column pair c/2, motif, c&1 (column 7 = 0); null = no structure side
     const double *thr_seq, *thr_struct;   // [nmp]
     int m, npair, nmp, ng, motif_base;
+    int ng_real;                          // motif groups of the pass that hold motifs (<= ng, the layout of its tables): the rest is skipped
+    // Teams: passes SIDE BY SIDE in one launch.  Workgroups [team_first[t], team_first[t + 1]) run pass t of n_teams
+    // consecutive passes whose tables lie stride_* elements apart (same ng layout) and whose motifs start nmp apart;
+    // team_first[t] = the grid for t >= n_teams.  n_teams <= 1: one pass, every workgroup (team_ng unused).
+    int n_teams;
+    int team_first[5];
+    int team_ng[4];                       // ng_real per team
+    int64_t stride_pairs, stride_letters, stride_pssm, stride_thr;      // in elements of the respective arrays
     // hits: LIB_SHARDS (or 1) regions of shard_cap slots, counters HIT_COUNTER_STRIDE words apart
     int64_t shard_cap;
     int hit_shards;

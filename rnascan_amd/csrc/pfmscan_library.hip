@@ -203,12 +203,13 @@ __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const
 // over after a drain.  A chunk brings one or two items per group at realistic thresholds, the queue takes >= 65.
 template <int K, int NG, int NP>
 __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos, const uint32_t cw,
-                                               uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
+                                               uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1, const int ng_real)
 {
     int g_next = NG;
     int qs = __builtin_amdgcn_readfirstlane(qn);      // the queue length is wave-uniform: keep it (and the branches on it) scalar
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+        if (g >= ng_real) break;                      // wave-uniform: the groups from here on hold no motif
         const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
@@ -232,11 +233,11 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 // Needs qn < 64 on entry (a group brings at most 64 items, the queue holds LIB_QCAP >= 127).
 template <int K, int NG, int NP>
 __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos, const uint32_t cw,
-                                               uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
+                                               uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1, const int ng_real)
 {
     int qs = __builtin_amdgcn_readfirstlane(qn);
     g = __builtin_amdgcn_readfirstlane(g);
-    while (g < NG && qs < 64) {
+    while (g < ng_real && qs < 64) {
         const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
@@ -254,44 +255,48 @@ __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP]
 // mask.  Nine groups out of ten have a flagged lane somewhere at realistic thresholds, so a push per (chunk, group) -- ballot,
 // branch, slot arithmetic, three LDS stores: ~15 VALU instructions next to the group's 19.5 -- made phase A VALU-bound
 // (+3.9 ms on C5).  Here a group adds one select and one OR; the chunk is pushed ONCE, a lane's item carries its group mask.
+// `ng_real` (wave-uniform, <= NG): groups from there on hold no motif (the last pass of a library in the common table layout).
 template <int K, int NG, int NP>
-__device__ __forceinline__ uint32_t lib_groupmask(const lds_cptr (&rowp)[NP])
+__device__ __forceinline__ uint32_t lib_groupmask(const lds_cptr (&rowp)[NP], const int ng_real)
 {
     uint32_t gm = 0u;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
-        const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x20080200u) != 0u;
-        gm |= flag ? (1u << g) : 0u;
+        if (g < ng_real) {                              // scalar compare + branch; always taken for full passes
+            const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
+            const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x20080200u) != 0u;
+            gm |= flag ? (1u << g) : 0u;
+        }
     }
     return gm;
 }
 
 template <int K, int NG, int NP>
-__device__ __forceinline__ uint32_t lib_dispatch_mask(const int npair, const lds_cptr (&rowp)[NP])
+__device__ __forceinline__ uint32_t lib_dispatch_mask(const int npair, const lds_cptr (&rowp)[NP], const int ng_real)
 {
     if constexpr (K >= NP) {
-        return lib_groupmask<NP, NG, NP>(rowp);
+        return lib_groupmask<NP, NG, NP>(rowp, ng_real);
     } else {
-        if (npair == K) return lib_groupmask<K, NG, NP>(rowp);
-        return lib_dispatch_mask<K + 1, NG, NP>(npair, rowp);
+        if (npair == K) return lib_groupmask<K, NG, NP>(rowp, ng_real);
+        return lib_dispatch_mask<K + 1, NG, NP>(npair, rowp, ng_real);
     }
 }
 
 // npair -> the K-row instantiation, over the pair counts of one width bucket (K = KLO .. NP)
 template <bool FAST, int K, int NG, int NP>
 __device__ __forceinline__ int lib_dispatch(const int npair, const int g, const lds_cptr (&rowp)[NP], int &qn,
-                                            const uint32_t relpos, const uint32_t cw, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1)
+                                            const uint32_t relpos, const uint32_t cw, uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1,
+                                            const int ng_real)
 {
     if constexpr (K >= NP) {
-        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
-        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+        if (FAST) return lib_octets_fast<NP, NG, NP>(rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
+        return lib_octets_slow<NP, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
     } else {
         if (npair == K) {
-            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
-            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+            if (FAST) return lib_octets_fast<K, NG, NP>(rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
+            return lib_octets_slow<K, NG, NP>(g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
         }
-        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+        return lib_dispatch<FAST, K + 1, NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
     }
 }
 
@@ -322,15 +327,31 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     uint32_t *q_p0 = q_pos + LIB_QCAP;
     uint32_t *q_p1 = q_p0 + LIB_QCAP;
 
+    // which pass this workgroup runs (teams: several passes of the library side by side in one launch, see LibArgs)
+    int team = 0, team_b0 = 0, team_grid = (int)gridDim.x, ng_real = a.ng_real;
+    if (a.n_teams > 1) {
+        const int bx = (int)blockIdx.x;
+        team = (bx >= a.team_first[1] ? 1 : 0) + (bx >= a.team_first[2] ? 1 : 0) + (bx >= a.team_first[3] ? 1 : 0);
+        team_b0 = team == 0 ? 0 : (team == 1 ? a.team_first[1] : (team == 2 ? a.team_first[2] : a.team_first[3]));
+        team_grid = (team == 0 ? a.team_first[1] : (team == 1 ? a.team_first[2] : (team == 2 ? a.team_first[3] : a.team_first[4]))) - team_b0;
+        ng_real = team == 0 ? a.team_ng[0] : (team == 1 ? a.team_ng[1] : (team == 2 ? a.team_ng[2] : a.team_ng[3]));
+    }
+    const uint32_t *g_pairs = a.pairs + (size_t)team * a.stride_pairs;
+    const double *g_letters = a.letters + (size_t)team * a.stride_letters;
+    const double *g_pssm = HAS_STRUCT ? a.pssm + (size_t)team * a.stride_pssm : nullptr;
+    const double *g_thr_seq = a.thr_seq + (size_t)team * a.stride_thr, *g_thr_struct = HAS_STRUCT ? a.thr_struct + (size_t)team * a.stride_thr : nullptr;
+    const int motif_base = a.motif_base + team * NMP;
+    const int bid = (int)blockIdx.x - team_b0;      // workgroup index inside the team
+
     for (int i = threadIdx.x; i < pair_bytes / 16; i += LIB_BLOCK)
-        reinterpret_cast<u32x4 *>(pairs)[i] = reinterpret_cast<const u32x4 *>(a.pairs)[i];
+        reinterpret_cast<u32x4 *>(pairs)[i] = reinterpret_cast<const u32x4 *>(g_pairs)[i];
     for (int i = threadIdx.x; i < NG * 16; i += LIB_BLOCK) reinterpret_cast<u32x4 *>(pairs)[pair_bytes / 16 + i] = u32x4{0u, 0u, 0u, 0u};
-    for (int i = threadIdx.x; i < m * 4 * NMP; i += LIB_BLOCK) letters[i] = a.letters[i];
+    for (int i = threadIdx.x; i < m * 4 * NMP; i += LIB_BLOCK) letters[i] = g_letters[i];
     if (HAS_STRUCT)
-        for (int i = threadIdx.x; i < m * 8 * NMP; i += LIB_BLOCK) pssm[i] = a.pssm[i];
+        for (int i = threadIdx.x; i < m * 8 * NMP; i += LIB_BLOCK) pssm[i] = g_pssm[i];
     for (int i = threadIdx.x; i < NMP; i += LIB_BLOCK) {
-        thr_s[i] = a.thr_seq[i];
-        thr_t[i] = HAS_STRUCT ? a.thr_struct[i] : -INFINITY;
+        thr_s[i] = g_thr_seq[i];
+        thr_t[i] = HAS_STRUCT ? g_thr_struct[i] : -INFINITY;
     }
     if (threadIdx.x == 0) *ticket = LIB_WAVES;      // the first chunk of wave w is chunk w
     __syncthreads();                                // the only workgroup barrier: waves are independent from here on
@@ -437,7 +458,11 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         if (HAS_STRUCT) {
             if (__builtin_amdgcn_ballot_w64(ok)) {
                 if (ok) {
+#ifdef LIB_DIAG_WRAP                                     // timing diagnostic only: the rows come from the first 2^20 positions (cache-resident): WRONG scores
+                    st = lib_struct_score<PROF_T, NMP>(a.profile, p & 0xFFFFF, m, pssm, mo);
+#else
                     st = lib_struct_score<PROF_T, NMP>(a.profile, p, m, pssm, mo);
+#endif
                     ok = st > thr_t[mo];
                 }
             }
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                 const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                 if ((int64_t)slot < a.shard_cap) {
                     a.hit_pos[shard_off + slot] = p + a.pos_offset;
-                    a.hit_motif[shard_off + slot] = a.motif_base + mo;
+                    a.hit_motif[shard_off + slot] = motif_base + mo;
                     a.hit_seq[shard_off + slot] = f;
                     if (HAS_STRUCT) a.hit_struct[shard_off + slot] = st;
                 }
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     // after this one is drawn before the chunk and read after it.
     int qn = 0;                                     // wave-uniform queue length (< 64 between chunks)
     constexpr int seg_shift = LIB_SEG_SHIFT - 6;    // chunks per segment (launch_library insists on seg_positions == 2^LIB_SEG_SHIFT)
-    const int64_t my_segs = blockIdx.x < a.n_seg ? (a.n_seg - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t my_segs = bid < a.n_seg ? (a.n_seg - bid + team_grid - 1) / team_grid : 0;
     const uint32_t n_units = (uint32_t)(my_segs << seg_shift);
     constexpr bool AHEAD = NP <= 8;                 // the wider buckets have no VGPR to hold the ticket across a chunk
     uint32_t drawn = 0;
@@ -482,8 +507,8 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
     for (uint32_t u = (uint32_t)wave; u < n_units; u = next_unit()) {
         if (AHEAD && lane == 0) drawn = atomicAdd(ticket, 1u);
         {
-            // segment blockIdx.x + (u >> seg_shift) gridDim.x, chunk u mod 2^seg_shift of it; relative to pos_base
-            const int64_t rel0 = ((int64_t)(blockIdx.x + (u >> seg_shift) * gridDim.x) << (seg_shift + 6)) +
+            // segment bid + (u >> seg_shift) team_grid, chunk u mod 2^seg_shift of it; relative to pos_base
+            const int64_t rel0 = ((int64_t)((uint32_t)bid + (u >> seg_shift) * (uint32_t)team_grid) << (seg_shift + 6)) +
                                  (int64_t)((u & ((1u << seg_shift) - 1u)) << 6);
             if (rel0 >= a.span) continue;                    // wave-uniform (the last segment may run over the span)
             const int64_t p0 = a.pos_base + rel0;            // multiple of 64
@@ -524,7 +549,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             const uint32_t relpos = (uint32_t)(rel0 + lane);
             if constexpr (MPG == 12) {
                 // all groups, then ONE push for the chunk: at most 64 items, and fewer than 64 were waiting -> always room
-                const uint32_t gm = lib_dispatch_mask<1, NG, NP>(npair, rowp);
+                const uint32_t gm = lib_dispatch_mask<1, NG, NP>(npair, rowp, ng_real);
                 const unsigned long long mk = __builtin_amdgcn_ballot_w64(gm != 0u);
                 if (mk) {                                    // wave-uniform
                     if (gm != 0u) {
@@ -540,14 +565,14 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                     qn += requeued - 64;
                 }
             } else {
-                int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+                int g = lib_dispatch<true, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, 0, rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
                 for (;;) {
                     while (qn >= 64) {                       // the top 64 items; the rest stays (LIFO)
                         dense(qn - 64, 64);
                         qn += requeued - 64;
                     }
-                    if (g >= NG) break;
-                    g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1);
+                    if (g >= ng_real) break;
+                    g = lib_dispatch<false, (NP == 8 ? 1 : NP / 2 + 1), NG, NP>(npair, g, rowp, qn, relpos, cw, q_pos, q_p0, q_p1, ng_real);
                 }
             }
         }

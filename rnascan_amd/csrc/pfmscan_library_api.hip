@@ -31,7 +31,8 @@ using namespace pfmscan;
 namespace {
 
 struct LibPass {
-    int motif_base = 0, n_real = 0, nmp = 0, ng = 0;
+    int motif_base = 0, n_real = 0, nmp = 0, ng = 0;      // ng: the group count its tables are laid out for (a kernel instantiation)
+    int ng_real = 0;           // groups that hold motifs (<= ng): the kernel skips the rest
     size_t pairs_off = 0;      // uint16 elements into d_pairs
     size_t letters_off = 0;    // doubles into d_letters
     size_t pssm_off = 0;       // doubles into d_pssm
@@ -209,7 +210,12 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
         LibPass ps;
         ps.motif_base = base;
         ps.n_real = std::min(n_motifs - base, ng_max * mpg);
-        ps.ng = lib_pick_ng(lib->np_bucket, (ps.n_real + mpg - 1) / mpg, ng_max);
+        ps.ng_real = (ps.n_real + mpg - 1) / mpg;
+        // seq + struct libraries of several passes: every pass in the layout of the full ones, so that
+        // the passes can run side by side in ONE launch of one kernel instantiation (lib_run: teams); the groups without
+        // motifs are skipped at run time
+        const bool uniform = lib->has_struct && n_motifs > ng_max * mpg;
+        ps.ng = uniform ? ng_max : lib_pick_ng(lib->np_bucket, ps.ng_real, ng_max);
         ps.nmp = ps.ng * mpg;
         ps.pairs_off = pairs_elems;
         ps.letters_off = letters_elems;
@@ -408,11 +414,47 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
         if (e != hipSuccess) return fail_hip(ctx, e, "launch k_profile_lib");
         return PFMSCAN_OK;
     }
+    // Teams: up to four consecutive passes SIDE BY SIDE in one launch, each on a share of the workgroups, all walking the
+    // stream at the same pace.  The structure verification reads ~every line of the profile through scattered loads; one
+    // pass after the other that is the whole profile from HBM per pass (3 x 8.4 GB on C5), side by side the later readers
+    // of a line find it in the memory-side cache (a diagnostic build whose rows come from a cache-resident region: C5
+    // -13 %, float64 rows -37 %: the upper bound).  Streams were tried first and dropped: concurrent kernels need a free
+    // hardware queue each and workgroup counts that are multiples of 8 per kernel (a grid is dealt round-robin to the 8
+    // XCDs and one workgroup too many on an XCD waits for a whole persistent kernel) -- 29 ms instead of 10.
+    const LibPass &first_pass = lib->passes[0];
+    bool teams = lib->has_struct && lib->passes.size() > 1 && n_pos >= (int64_t)8 * ctx->n_cu * LIB_SEG &&
+                 ctx->n_cu >= 16 && !std::getenv("PFMSCAN_LIB_SEQUENTIAL");
+    for (const LibPass &ps : lib->passes) teams = teams && ps.ng == first_pass.ng;      // the common layout (pfmscan_library_create)
     const int64_t max_span = (int64_t)1 << 31;
     for (int64_t base = 0; base < n_pos; base += max_span) {
-        for (const LibPass &ps : lib->passes) {
+        // a team launch needs the whole grid (a short last span of a very long stream runs its passes one by one)
+        const int64_t span_segs = (std::min<int64_t>(max_span, n_pos - base) + LIB_SEG - 1) / LIB_SEG;
+        const size_t per_launch = teams && span_segs >= ctx->n_cu ? 4 : 1;
+        for (size_t p0 = 0; p0 < lib->passes.size(); p0 += per_launch) {
+            const LibPass &ps = lib->passes[p0];
+            const size_t nt = std::min(per_launch, lib->passes.size() - p0);
             LibArgs a;
             std::memset(&a, 0, sizeof(a));
+            a.ng_real = ps.ng_real;
+            if (nt > 1) {
+                // shares of the grid ~ the cost of a pass: measured 0.385 ms per motif group + 0.66 ms on C5
+                double w[4] = {0, 0, 0, 0}, wsum = 0;
+                // (flat around it: 0 .. 1.5 for the constant give the same time within the noise)
+                for (size_t t = 0; t < nt; ++t) wsum += (w[t] = 0.385 * lib->passes[p0 + t].ng_real + 0.66);
+                a.n_teams = (int)nt;
+                int placed = 0;
+                for (size_t t = 0; t < nt; ++t) {
+                    a.team_first[t] = placed;
+                    a.team_ng[t] = lib->passes[p0 + t].ng_real;
+                    const int share = t + 1 == nt ? ctx->n_cu - placed : std::max(1, (int)std::lround(ctx->n_cu * w[t] / wsum));
+                    placed += share;
+                }
+                for (size_t t = nt; t < 5; ++t) a.team_first[t] = ctx->n_cu;
+                a.stride_pairs = (int64_t)(lib->passes[p0 + 1].pairs_off - ps.pairs_off) / 2;        // uint16 elements -> dwords
+                a.stride_letters = (int64_t)(lib->passes[p0 + 1].letters_off - ps.letters_off);
+                a.stride_pssm = (int64_t)(lib->passes[p0 + 1].pssm_off - ps.pssm_off);
+                a.stride_thr = (int64_t)(lib->passes[p0 + 1].thr_off - ps.thr_off);
+            }
             a.codes = d_codes;
             a.profile = lib->has_struct ? d_profile : nullptr;
             a.profile_dtype = profile_dtype;
