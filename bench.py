@@ -169,7 +169,8 @@ def library_roofline(info, windows, n_motifs, width, records, length, kernel_ms,
         "frac": lds_read / (kernel_ms * 1e-3) / 1e9 / lds_peak, "traffic": lds_read,
         "traffic_source": "computed, not measured: 16-byte table entries of %d motifs read by phase A (LDS, not HBM, bytes); "
                           "the exact pass's gathers come on top" % mpg,
-        "kernel": "k_library (x%d passes of <= %d motifs)" % (info["passes"], info["motifs_per_pass"]),
+        "kernel": "k_library (%d passes of <= %d motifs; on a long stream they run side by side as teams of one launch)" % (
+            info["passes"], info["motifs_per_pass"]),
         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": lds_read,
         "algorithmic_unit": "LDS bytes the phase-A look-ups move: windows x motif groups x ceil(w/2) x 16 B",
         "nominal_2B_per_credit_frac": nominal / (kernel_ms * 1e-3) / 1e9 / lds_peak,
