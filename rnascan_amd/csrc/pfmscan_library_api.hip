@@ -446,7 +446,8 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
                 for (size_t t = 0; t < nt; ++t) {
                     a.team_first[t] = placed;
                     a.team_ng[t] = lib->passes[p0 + t].ng_real;
-                    const int share = t + 1 == nt ? ctx->n_cu - placed : std::max(1, (int)std::lround(ctx->n_cu * w[t] / wsum));
+                    const int room = ctx->n_cu - placed - (int)(nt - 1 - t);       // every later team keeps at least one workgroup
+                    const int share = t + 1 == nt ? ctx->n_cu - placed : std::min(room, std::max(1, (int)std::lround(ctx->n_cu * w[t] / wsum)));
                     placed += share;
                 }
                 for (size_t t = nt; t < 5; ++t) a.team_first[t] = ctx->n_cu;
