@@ -5,6 +5,8 @@ checked through size-independent properties plus an oracle comparison of sampled
   * hits mode finds exactly the windows the all-scores output says pass the thresholds
   * 64 records picked at random score the same inside the 300M-position stream as on their
     own through the host API, and match the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,6 +226,22 @@ def test_fullsize_c5_library_equals_all_scores(big, oracle):
         assert torch.equal(hp[:k][idx], want)
         assert torch.equal(hs[:k][idx].view(torch.int32), out_seq[want].view(torch.int32))
         assert float((ht[:k][idx] - out_st[want]).abs().max()) <= 1e-6
+    # the three passes ran side by side as teams of one launch (a stream this long); one after the other: the same hits
+    os.environ["PFMSCAN_LIB_SEQUENTIAL"] = "1"
+    try:
+        hm2 = torch.empty(cap, dtype=torch.int32, device=dev)
+        hp2 = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt.zero_()
+        torch.cuda.synchronize()
+        ctx.library_hits_dev(lib, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, thr_s, thr_t, cap,
+                             hp2.data_ptr(), hm2.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
+        ctx.synchronize()
+    finally:
+        del os.environ["PFMSCAN_LIB_SEQUENTIAL"]
+    assert int(cnt.item()) == k
+    assert torch.equal(torch.bincount(hm2[:k].long(), minlength=n), per_motif)
+    key = lambda pos, mot: torch.sort(pos * n + mot.long()).values
+    assert torch.equal(key(hp[:k], hm[:k]), key(hp2[:k], hm2[:k]))
     lib.close()
 
 
