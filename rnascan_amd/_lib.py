@@ -20,7 +20,8 @@ PROFILE_NONE, PROFILE_F32, PROFILE_F64 = 0, 1, 2
 SEP = 7
 NCODE = 8
 NSTRUCT = 7
-MAX_M = 64
+MAX_M = 64            # widest PFM of the tuned kernels and of PFM libraries
+MAX_WIDTH = 4096      # widest PFM accepted (wider than MAX_M: the plain rolled-loop kernel)
 ABI_VERSION = 4
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)

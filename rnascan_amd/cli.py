@@ -119,12 +119,13 @@ def load_motif(pfm_file, pseudocount, letters, background):
     fasta.eprint("Found %d motifs" % len(motifs_set))
     if len(motifs_set) == 0:
         raise ValueError("No motifs found.")
-    from ._lib import MAX_M
-    wide = [(k, v.length) for k, v in motifs_set.items() if v.length > MAX_M]
+    from ._lib import MAX_WIDTH
+    wide = [(k, v.length) for k, v in motifs_set.items() if v.length > MAX_WIDTH]
     if wide:
-        # the reference's loops take any width (_pwm.c:34-68); the kernels here are unrolled for widths up to PFMSCAN_MAX_M
+        # the reference's loops take any width (_pwm.c:34-68); here widths up to PFMSCAN_MAX_M run the tuned kernels, wider
+        # ones a plain rolled-loop kernel, up to PFMSCAN_MAX_WIDTH
         fasta.eprint("PFM %s in %s is %d positions wide: this build scans PFMs of at most %d positions "
-                     "(PFMSCAN_MAX_M, include/pfmscan.h)" % (wide[0][0], pfm_file, wide[0][1], MAX_M))
+                     "(PFMSCAN_MAX_WIDTH, include/pfmscan.h)" % (wide[0][0], pfm_file, wide[0][1], MAX_WIDTH))
         sys.exit(1)
     return motifs_set
 

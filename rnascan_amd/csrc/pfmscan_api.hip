@@ -155,8 +155,8 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
     if (!ctx || !out) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_motif_create: NULL argument");
     *out = nullptr;
     if (!letter_table && !struct_pssm) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_motif_create: no table given");
-    if (m < 1 || m > PFMSCAN_MAX_M)
-        return fail(ctx, PFMSCAN_E_BADSHAPE, "PFM width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    if (m < 1 || m > PFMSCAN_MAX_WIDTH)
+        return fail(ctx, PFMSCAN_E_BADSHAPE, "PFM width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_WIDTH));
     if (letter_table) {
         for (int j = 0; j < m; ++j)
             if (!std::isnan(letter_table[j * 8 + PFMSCAN_SEP]))
@@ -663,8 +663,8 @@ int pfmscan_pwm_calculate(pfmscan_ctx *ctx, const char *sequence, int64_t s, con
 {
     if (!ctx) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx");
     if (!sequence || !matrix || s < 0) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_pwm_calculate: NULL or negative argument");
-    if (m < 1 || m > PFMSCAN_MAX_M)
-        return fail(ctx, PFMSCAN_E_BADSHAPE, "position-weight matrix width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    if (m < 1 || m > PFMSCAN_MAX_WIDTH)
+        return fail(ctx, PFMSCAN_E_BADSHAPE, "position-weight matrix width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_WIDTH));
     const int64_t n = s - m + 1;
     if (n <= 0) return PFMSCAN_OK;
     if (!out) return fail(ctx, PFMSCAN_E_BADARG, "out is NULL");

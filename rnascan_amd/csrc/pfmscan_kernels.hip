@@ -1698,10 +1698,75 @@ static hipError_t launch_profile_t(const ScanArgs &a, const Tuning &t, hipStream
     return launch_profile_v<5, HAS_SEQ, PROF_T, 0>(a, stream);
 }
 
+// ---------------------------------------------------------------------------
+// k_wide -- PFMs wider than PFMSCAN_MAX_M (the reference's loops take any width: _pwm.c:34-68, rnascan.py:302-307).
+// The tuned kernels are unrolled and sized for widths up to 64; a wider motif -- none of the reference's examples is --
+// takes this plain form: one thread per window, rolled loops over the motif rows in the reference's operation order
+// (sequential fp64 sum of the letter table; per row d = r0 * s0, six FMAs, score += nan_to_num(d)), rows and codes
+// straight from global memory (neighbouring threads read neighbouring bytes / rows; the tables through the caches).
+// Same outputs and hit rule as k_letters / k_profile in every mode.  No roofline claim: O(m) dependent loads per window.
+// ---------------------------------------------------------------------------
+template <typename PROF_T>
+__global__ __launch_bounds__(BLOCK) void k_wide(const ScanArgs a)
+{
+    const int m = a.m;
+    const int64_t n_pos = a.n_pos;
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool in = p < n_pos;
+    const bool has_seq = a.letter_table != nullptr, has_st = a.struct_pssm != nullptr;
+    double sq = 0.0, st = 0.0;
+    if (in && has_seq) {
+#pragma unroll 4
+        for (int j = 0; j < m; ++j) {
+            const uint32_t c = p + j < n_pos ? (uint32_t)a.codes[p + j] & 7u : (uint32_t)PFMSCAN_SEP;     // past the end: NaN column
+            sq += a.letter_table[j * 8 + c];
+        }
+    }
+    if (in && has_st) {
+        if (p + m > n_pos) {
+            st = __longlong_as_double(0x7ff8000000000000ll);       // the window runs past the stream end
+        } else {
+            const PROF_T *__restrict__ row = reinterpret_cast<const PROF_T *>(a.profile) + p * 7;
+            const __attribute__((address_space(4))) double *pssm = (const __attribute__((address_space(4))) double *)a.struct_pssm;
+#pragma unroll 2
+            for (int j = 0; j < m; ++j) {
+                double d = (double)row[j * 7] * pssm[j * 7];
+#pragma unroll
+                for (int k = 1; k < 7; ++k) d = fma((double)row[j * 7 + k], pssm[j * 7 + k], d);
+                st += nan_to_num(d);
+            }
+        }
+    }
+    if (a.hits) {
+        bool pass = in;
+        if (has_st) pass = pass && (st > a.thr_struct);
+        if (has_seq) pass = pass && ((double)(float)sq > a.thr_seq);
+        // a letters-only scan reports its fp64 score in hit_struct (k_letters does), a scan with a structure part the structure score
+        emit_hits_block<1>(pass ? 1u : 0u, [&](int) { return p; }, [&](int) { return (float)sq; }, [&](int) { return has_st ? st : sq; }, a);
+        return;
+    }
+    if (!in) return;
+    if (has_seq && a.out_seq) a.out_seq[p] = (float)sq;
+    if (has_seq && a.out_letters_f64) a.out_letters_f64[p] = sq;
+    if (has_st && a.out_struct) a.out_struct[p] = st;
+}
+
+static hipError_t launch_wide(const ScanArgs &a, hipStream_t stream)
+{
+    if ((a.letter_table && !a.codes) || (a.struct_pssm && !a.profile)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((a.n_pos + BLOCK - 1) / BLOCK);
+    if (a.struct_pssm && a.profile_dtype == PFMSCAN_PROFILE_F64)
+        hipLaunchKernelGGL(k_wide<double>, dim3(grid), dim3(BLOCK), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_wide<float>, dim3(grid), dim3(BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what)
 {
     *what = "launch";
     if (a.n_pos <= 0) return hipSuccess;
+    if (a.m > PFMSCAN_MAX_M) return launch_wide(a, stream);
     if (!a.struct_pssm) return launch_letters(a, t, stream);
     if (a.out_letters_f64 || a.profile == nullptr) return hipErrorInvalidValue;
     const bool has_seq = a.letter_table != nullptr;

@@ -20,6 +20,7 @@ from .pssm import PSSM
 
 SEQ_COLUMNS = ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds"]
 PIPELINE_CHUNK = int(os.environ.get("RNASCAN_PIPELINE_CHUNK", str(1 << 24)))     # positions per chunk of the host pipeline
+LIBRARY_MAX_M = 64                                                                # PFMSCAN_MAX_M: wider PFMs are scanned one by one (the plain kernel)
 PIPELINE_MIN = 2 * PIPELINE_CHUNK                                                 # shorter streams are staged whole
 
 
@@ -261,7 +262,7 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
     for motif_id in sorted(pssm.keys()) if len(pssm) > 1 else list(pssm.keys()):
         by_width.setdefault(pssm[motif_id].length, []).append(motif_id)
     for m, mids in by_width.items():
-        if is_rna and len(mids) > 1 and np.isfinite(float(minscore)):
+        if is_rna and len(mids) > 1 and np.isfinite(float(minscore)) and m <= LIBRARY_MAX_M:
             T = np.stack([pssm[i].letter_table(order) for i in mids])
             pos, mo, sq, _ = engine.library_hits(stream, T, None, float(minscore), one_shot=len(by_width) == 1)
             tables.append(rows(mids, m, pos, mo, np.round(sq, 3)))
@@ -332,7 +333,7 @@ def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing, 
     for motif_id in sorted(pssm.keys()) if len(pssm) > 1 else list(pssm.keys()):
         by_width.setdefault(pssm[motif_id].length, []).append(motif_id)
     for m, mids in by_width.items():
-        if len(mids) > 1 and np.isfinite(thr) and hasattr(engine, "library_hits"):
+        if len(mids) > 1 and np.isfinite(thr) and hasattr(engine, "library_hits") and m <= LIBRARY_MAX_M:
             P = np.stack([struct_matrix(pssm[i], list(letters), pairing) for i in mids])
             pos, mo, _, st = engine.library_hits(stream, None, P, None, thr, one_shot=len(by_width) == 1)
             tables.append(rows(mids, m, pos, mo, st))
@@ -491,7 +492,7 @@ def _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, st
     for m, group in by_width.items():
         tabs = [seq_pssm[a].letter_table(pack.RNA_LETTERS) for a, _ in group]
         pssms = [struct_matrix(struct_pssm[b], letters0, pairing) for _, b in group]
-        if len(group) > 1 and np.isfinite(thr):
+        if len(group) > 1 and np.isfinite(thr) and m <= LIBRARY_MAX_M:
             pos, mo, sq, st = engine.library_hits(stream, np.stack(tabs), np.stack(pssms), thr, thr, one_shot=len(by_width) == 1)
             parts = [(pos, mo, sq, st)]
         else:

@@ -45,7 +45,7 @@ int main(void)
         }
     }
     /* error convention: width out of range -> BADSHAPE with a message */
-    if (pfmscan_pwm_calculate(ctx, seq, s, &M[0][0], 65, got) != PFMSCAN_E_BADSHAPE || !strlen(pfmscan_last_error(ctx))) bad++;
+    if (pfmscan_pwm_calculate(ctx, seq, s, &M[0][0], PFMSCAN_MAX_WIDTH + 1, got) != PFMSCAN_E_BADSHAPE || !strlen(pfmscan_last_error(ctx))) bad++;
     pfmscan_ctx_destroy(ctx);
     printf(bad ? "FAIL\n" : "OK %lld windows\n", (long long)(s - m + 1));
     return bad ? 1 : 0;

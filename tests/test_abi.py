@@ -36,6 +36,7 @@ def test_header_constants_match_bindings():
     assert int(consts["PFMSCAN_NCODE"]) == _lib.NCODE
     assert int(consts["PFMSCAN_NSTRUCT"]) == _lib.NSTRUCT
     assert int(consts["PFMSCAN_MAX_M"]) == _lib.MAX_M
+    assert int(consts["PFMSCAN_MAX_WIDTH"]) == _lib.MAX_WIDTH
     assert int(consts["PFMSCAN_E_CAPACITY"]) == _lib.E_CAPACITY
     assert int(consts["PFMSCAN_PROFILE_F64"]) == _lib.PROFILE_F64
 

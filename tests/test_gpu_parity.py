@@ -67,16 +67,20 @@ def test_pwm_calculate_argument_errors(ctx):
     with pytest.raises(ValueError):
         ctx.pwm_calculate("ACGU", np.zeros(4))                             # _pwm.c:101-106
     with pytest.raises(ValueError):
-        ctx.pwm_calculate("A" * 100, np.zeros((65, 4)))                    # wider than PFMSCAN_MAX_M
+        ctx.pwm_calculate("A" * 5000, np.zeros((4097, 4)))                 # wider than PFMSCAN_MAX_WIDTH
 
 
-@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8, 12, 15, 16, 17, 18, 31, 32, 33, 48, 64])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8, 12, 15, 16, 17, 18, 31, 32, 33, 48, 64, 65, 100, 257])
 def test_pwm_calculate_vs_oracle_widths(ctx, oracle, m):
     rng = np.random.default_rng(1000 + m)
     letters = np.array(list("ACGUacgutTN-"))
     for L in (m, m + 1, m + 3, 255, 1024, 1027, 4096 + 5, 20011):
         seq = "".join(rng.choice(letters, size=L, p=[.2, .2, .2, .2, .03, .03, .03, .03, .03, .02, .02, .01]))
         M = rng.normal(0, 3, size=(m, 4))
+        if L < m - 1:                                   # a negative output shape: MemoryError in the reference (_pwm.c:26-31)
+            with pytest.raises(MemoryError):
+                ctx.pwm_calculate(seq, M)
+            continue
         assert_f32_bits_equal(ctx.pwm_calculate(seq, M), oracle.pwm_calculate(seq, M))
 
 

@@ -243,16 +243,17 @@ def test_tsv_writer_quotes_like_to_csv():
 
 
 def test_cli_says_why_a_pfm_wider_than_the_kernels_is_refused(tmp_path, capsys):
-    """the reference's loops take any PFM width (_pwm.c:34-68); this build stops at PFMSCAN_MAX_M with a clear message"""
+    """the reference's loops take any PFM width (_pwm.c:34-68); this build stops at PFMSCAN_MAX_WIDTH with a clear message
+    (widths above PFMSCAN_MAX_M = 64 run the plain kernel: tests/test_gpu_wide.py)"""
     import pytest
     from rnascan_amd import _lib, cli, fasta
     pfm = tmp_path / "wide.pfm"
     with open(pfm, "w") as f:
         f.write("PO\tA\tC\tG\tU\n")
-        for i in range(_lib.MAX_M + 1):
+        for i in range(_lib.MAX_WIDTH + 1):
             f.write("%d\t0.25\t0.25\t0.25\t0.25\n" % i)
     with pytest.raises(SystemExit) as e:
         cli.load_motif(str(pfm), 0.01, fasta.RNA, None)
     assert e.value.code == 1
     err = capsys.readouterr().err
-    assert "%d positions wide" % (_lib.MAX_M + 1) in err and "at most %d" % _lib.MAX_M in err
+    assert "%d positions wide" % (_lib.MAX_WIDTH + 1) in err and "at most %d" % _lib.MAX_WIDTH in err
