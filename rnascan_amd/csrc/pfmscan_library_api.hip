@@ -437,10 +437,12 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
             std::memset(&a, 0, sizeof(a));
             a.ng_real = ps.ng_real;
             if (nt > 1) {
-                // shares of the grid ~ the cost of a pass: measured 0.385 ms per motif group + 0.66 ms on C5
+                // shares of the grid ~ the cost of a pass: measured 0.385 ms per motif group + 0.66 ms on C5 with float32 rows
+                // (flat around it: 0 .. 1.5 for the constant give the same time within the noise); with float64 rows the
+                // part that does not scale with the groups is larger (88 / 88 / 80 workgroups beat 92 / 92 / 72 by 4 %)
                 double w[4] = {0, 0, 0, 0}, wsum = 0;
-                // (flat around it: 0 .. 1.5 for the constant give the same time within the noise)
-                for (size_t t = 0; t < nt; ++t) wsum += (w[t] = 0.385 * lib->passes[p0 + t].ng_real + 0.66);
+                const double fixed = profile_dtype == PFMSCAN_PROFILE_F64 ? 3.0 : 0.66;
+                for (size_t t = 0; t < nt; ++t) wsum += (w[t] = 0.385 * lib->passes[p0 + t].ng_real + fixed);
                 a.n_teams = (int)nt;
                 int placed = 0;
                 for (size_t t = 0; t < nt; ++t) {
