@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 4
+#define PFMSCAN_ABI_VERSION 5
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -301,6 +301,14 @@ int pfmscan_debug_quad_table(const double *letter_table, int m, double thr_seq, 
 #define PFMSCAN_UPLOAD_RUNTIME 0
 #define PFMSCAN_UPLOAD_STAGED  1
 int pfmscan_set_upload_mode(pfmscan_ctx *ctx, int mode);
+/* Tell the staged uploader that the host range [base, base + length) is a read-only MAPPING of `path` starting at byte
+ * `file_offset` of that file (what numpy.memmap / mmap give the caller for a packed profile store).  A staged transfer
+ * whose source lies inside the range then READS THE FILE (pread into the pinned buffers) instead of touching the mapping:
+ * no page faults, no page-table entries to build and to tear down again -- unmapping an 8.4 GB store that was uploaded
+ * through its mapping costs up to 0.2 s of munmap at exit on a box whose tmpfs / page cache has no huge pages.  The bytes
+ * are the same either way.  length == 0 (path may be NULL) forgets the range: do that BEFORE unmapping it.  At most 8
+ * ranges per context; a ninth replaces the oldest. */
+int pfmscan_upload_source_file(pfmscan_ctx *ctx, const void *base, size_t length, const char *path, int64_t file_offset);
 
 /* ---- host ingest and output (no device needed; no context: errors via pfmscan_last_error(NULL)) ---------------
  * The two pieces of host work that dwarf the kernel at scale, in native code.

@@ -22,7 +22,7 @@ NCODE = 8
 NSTRUCT = 7
 MAX_M = 64            # widest PFM of the tuned kernels and of PFM libraries
 MAX_WIDTH = 4096      # widest PFM accepted (wider than MAX_M: the plain rolled-loop kernel)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -35,7 +35,7 @@ SYMBOLS = [
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
     "pfmscan_debug_quad_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
-    "pfmscan_set_upload_mode", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
+    "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -126,6 +126,7 @@ def load():
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, i32, vp, ctypes.POINTER(dbl)]
     L.pfmscan_debug_quad_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
     L.pfmscan_set_upload_mode.argtypes = [vp, i32]
+    L.pfmscan_upload_source_file.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
@@ -160,6 +161,16 @@ def is_file_mapping(a):
             return True
         a = getattr(a, "base", None)
     return False
+
+
+def root_memmap(a):
+    """the numpy.memmap an array is (a view of) -- the one that owns the mapping and knows its file -- or None"""
+    root = None
+    while a is not None:
+        if isinstance(a, np.memmap) and getattr(a, "filename", None) is not None:
+            root = a
+        a = getattr(a, "base", None)
+    return root
 
 
 def _raise(L, ctx, rc, n_hits=None):
@@ -458,6 +469,32 @@ class Context(object):
         if mode != getattr(self, "_upload_mode", 0):
             self._check(self._L.pfmscan_set_upload_mode(self._h, mode))
             self._upload_mode = mode
+        if mode:
+            for a in arrays:
+                self._register_mapping(root_memmap(a))
+
+    def _register_mapping(self, mm):
+        """tell the uploader which file a read-only numpy.memmap maps (pfmscan_upload_source_file): staged transfers then
+        pread the file and never touch the mapping (no page faults, nothing to unmap page by page at exit).  The range is
+        forgotten again just before the memmap goes away."""
+        import weakref
+        if mm is None or getattr(mm, "mode", "r") not in ("r", "c") or mm.nbytes == 0:
+            return
+        known = self.__dict__.setdefault("_mappings", {})
+        base = mm.ctypes.data
+        if base in known:
+            return
+        rc = self._L.pfmscan_upload_source_file(self._h, ctypes.c_void_p(base), mm.nbytes, os.fsencode(str(mm.filename)), int(mm.offset))
+        if rc:
+            return                                      # not fatal: the mapping itself is still a valid source
+        ctx_ref = weakref.ref(self)
+
+        def forget(base=base):
+            ctx = ctx_ref()
+            if ctx is not None and getattr(ctx, "_h", None):
+                ctx._L.pfmscan_upload_source_file(ctx._h, ctypes.c_void_p(base), 0, None, 0)
+                ctx.__dict__.get("_mappings", {}).pop(base, None)
+        known[base] = weakref.finalize(mm, forget)
 
     # -- staged stream: upload once, run many motifs ------------------------------------
     def stage(self, codes=None, profile=None):

@@ -46,6 +46,16 @@ struct pfmscan_ctx {
     DevBuf lib_pos, lib_motif, lib_seq, lib_struct, lib_count;   // library scans: sharded hits of the _dev form
     DevBuf pipe_codes[2], pipe_profile[2];      // chunked host pipeline: double-buffered chunk of the stream
     hipEvent_t pipe_copied[2] = {nullptr, nullptr}, pipe_scanned[2] = {nullptr, nullptr};
+    // host ranges known to be read-only mappings of files (pfmscan_upload_source_file): the staged uploader preads them
+    struct FileRange {
+        const unsigned char *base = nullptr;
+        size_t length = 0;
+        int fd = -1;
+        int64_t offset = 0;
+    };
+    static constexpr int N_FILE_RANGES = 8;
+    FileRange file_ranges[N_FILE_RANGES];
+    int file_range_next = 0;
     pfmscan::Uploader *up = nullptr;
     int upload_mode = PFMSCAN_UPLOAD_RUNTIME;
     // staged stream (pfmscan_stage)

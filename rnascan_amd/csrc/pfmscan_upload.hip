@@ -7,7 +7,11 @@
 // stream and the source may be reused as soon as upload() returns.  Anonymous memory gains nothing (the runtime's
 // in-place pinning already reaches the PCIe rate), so the staged path is a MODE the caller selects for sources it knows
 // to be file mappings (pfmscan_set_upload_mode; rnascan_amd/_lib.py does it for numpy memmaps).
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +49,20 @@ static void copy_slice(unsigned char *d, const unsigned char *s, size_t n, bool 
 #endif
 }
 
+// the same bytes from the file behind the mapping: no page of the mapping is touched.  false: fall back to the mapping
+static bool read_slice(unsigned char *d, int fd, int64_t off, size_t n)
+{
+    while (n > 0) {
+        const ssize_t got = pread(fd, d, n, (off_t)off);
+        if (got < 0 && errno == EINTR) continue;
+        if (got <= 0) return false;                    // error or a file shorter than its mapping
+        d += got;
+        off += got;
+        n -= (size_t)got;
+    }
+    return true;
+}
+
 struct Uploader {
     static constexpr int NBUF = 3;
     size_t PIECE = (size_t)64 << 20;
@@ -61,6 +79,8 @@ struct Uploader {
     const unsigned char *src = nullptr;
     unsigned char *dst = nullptr;
     size_t bytes = 0;
+    int src_fd = -1;                       // >= 0: [src, src + bytes) is file src_fd from src_off on
+    int64_t src_off = 0;
     uint64_t gen = 0;
     int pending = 0;
     bool quit = false;
@@ -72,6 +92,8 @@ struct Uploader {
             const unsigned char *s;
             unsigned char *d;
             size_t nb;
+            int fd;
+            int64_t foff;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return quit || gen != seen; });
@@ -80,9 +102,11 @@ struct Uploader {
                 s = src;
                 d = dst;
                 nb = bytes;
+                fd = src_fd;
+                foff = src_off;
             }
             const size_t a = (nb * (size_t)w / (size_t)n) & ~(size_t)4095, b = w + 1 == n ? nb : (nb * (size_t)(w + 1) / (size_t)n) & ~(size_t)4095;
-            if (b > a) copy_slice(d + a, s + a, b - a, nt);
+            if (b > a && !(fd >= 0 && read_slice(d + a, fd, foff + (int64_t)a, b - a))) copy_slice(d + a, s + a, b - a, nt);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (--pending == 0) cv_done.notify_one();
@@ -90,12 +114,14 @@ struct Uploader {
         }
     }
 
-    void copy(void *d, const void *s, size_t nb)
+    void copy(void *d, const void *s, size_t nb, int fd = -1, int64_t foff = 0)
     {
         std::unique_lock<std::mutex> lk(mu);
         src = static_cast<const unsigned char *>(s);
         dst = static_cast<unsigned char *>(d);
         bytes = nb;
+        src_fd = fd;
+        src_off = foff;
         pending = (int)workers.size();
         ++gen;
         cv_work.notify_all();
@@ -156,12 +182,22 @@ int upload(pfmscan_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipSt
         HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
         return PFMSCAN_OK;
     }
+    // a source inside a range registered as a file mapping is read from the file
+    int fd = -1;
+    int64_t foff = 0;
+    const unsigned char *hs = static_cast<const unsigned char *>(h_src);
+    if (!std::getenv("PFMSCAN_UPLOAD_NO_PREAD"))
+        for (const pfmscan_ctx::FileRange &fr : ctx->file_ranges)
+            if (fr.fd >= 0 && hs >= fr.base && hs + bytes <= fr.base + fr.length) {
+                fd = fr.fd;
+                foff = fr.offset + (int64_t)(hs - fr.base);
+            }
     for (size_t off = 0; off < bytes; off += up->PIECE) {
         const size_t nb = std::min(up->PIECE, bytes - off);
         const int b = up->next;
         up->next = (b + 1) % Uploader::NBUF;
         if (up->busy[b]) HIP_TRY(ctx, hipEventSynchronize(up->done[b]));       // its previous piece has left the buffer
-        up->copy(up->pinned[b], static_cast<const unsigned char *>(h_src) + off, nb);
+        up->copy(up->pinned[b], hs + off, nb, fd, foff + (int64_t)off);
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<unsigned char *>(d_dst) + off, up->pinned[b], nb, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipEventRecord(up->done[b], st));
         up->busy[b] = true;
@@ -178,12 +214,45 @@ extern "C" int pfmscan_set_upload_mode(pfmscan_ctx *ctx, int mode)
     return PFMSCAN_OK;
 }
 
+extern "C" int pfmscan_upload_source_file(pfmscan_ctx *ctx, const void *base, size_t length, const char *path, int64_t file_offset)
+{
+    if (!ctx || !base) return pfmscan::fail(ctx, PFMSCAN_E_BADARG, "pfmscan_upload_source_file: NULL argument");
+    const unsigned char *b = static_cast<const unsigned char *>(base);
+    for (pfmscan_ctx::FileRange &fr : ctx->file_ranges)       // a range with this base is replaced or forgotten
+        if (fr.fd >= 0 && fr.base == b) {
+            (void)close(fr.fd);
+            fr = pfmscan_ctx::FileRange();
+        }
+    if (length == 0) return PFMSCAN_OK;
+    if (!path || file_offset < 0) return pfmscan::fail(ctx, PFMSCAN_E_BADARG, "pfmscan_upload_source_file: no path / negative offset");
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return pfmscan::fail(ctx, PFMSCAN_E_BADARG, std::string("pfmscan_upload_source_file: cannot open ") + path);
+    pfmscan_ctx::FileRange *slot = nullptr;
+    for (pfmscan_ctx::FileRange &fr : ctx->file_ranges)
+        if (fr.fd < 0 && !slot) slot = &fr;
+    if (!slot) {                                              // full: the oldest goes
+        slot = &ctx->file_ranges[ctx->file_range_next];
+        ctx->file_range_next = (ctx->file_range_next + 1) % pfmscan_ctx::N_FILE_RANGES;
+        (void)close(slot->fd);
+    }
+    slot->base = b;
+    slot->length = length;
+    slot->fd = fd;
+    slot->offset = file_offset;
+    return PFMSCAN_OK;
+}
+
 namespace pfmscan {
 
 void upload_release(pfmscan_ctx *ctx)
 {
     delete ctx->up;
     ctx->up = nullptr;
+    for (pfmscan_ctx::FileRange &fr : ctx->file_ranges)
+        if (fr.fd >= 0) {
+            (void)close(fr.fd);
+            fr = pfmscan_ctx::FileRange();
+        }
 }
 
 }  // namespace pfmscan

@@ -406,3 +406,38 @@ def test_mapped_store_of_300_mb_takes_the_staged_upload_by_itself(ctx, tmp_path,
     ctx.stage(None, prof)                                    # and back to the runtime's copy for ordinary memory
     assert ctx._upload_mode == 0
     motif.close()
+
+
+def test_staged_upload_reads_the_file_behind_a_mapping(ctx, tmp_path, monkeypatch):
+    """a numpy.memmap source is registered with the uploader (pfmscan_upload_source_file) and staged transfers pread the
+    file instead of touching the mapping: same scores as from memory for a memmap that starts at a file offset, for a
+    view into it, and with the pread path switched off; the range is forgotten when the memmap goes away"""
+    import gc
+    from test_gpu_parity import rand_struct_pssm
+    monkeypatch.setenv("PFMSCAN_UPLOAD", "1")                 # staged from 32 MB on
+    rng = np.random.default_rng(5)
+    n_pos, lead = 1_500_011, 4096 + 28 * 3                    # 42 MB of rows behind a 4180-byte header
+    prof = rng.random((n_pos, 7), dtype=np.float32)
+    path = str(tmp_path / "with_header.bin")
+    with open(path, "wb") as f:
+        f.write(b"\x5a" * lead)
+        prof.tofile(f)
+    mapped = np.memmap(path, dtype=np.float32, mode="r", offset=lead, shape=(n_pos, 7))
+    motif = ctx.motif(None, rand_struct_pssm(rng, 12, inf_frac=0.0))
+    _, want = ctx.scan_host(motif, None, prof, want_seq=False)
+    before = len(ctx.__dict__.get("_mappings", {}))
+    _, got = ctx.scan_host(motif, None, mapped, want_seq=False)
+    assert len(ctx._mappings) == before + 1                   # registered on first use
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    a, b = 100_003, 1_400_001                                 # a view: the source pointer lies inside the range
+    _, got = ctx.scan_host(motif, None, mapped[a:b], want_seq=False)
+    _, want_view = ctx.scan_host(motif, None, prof[a:b], want_seq=False)
+    assert np.array_equal(got.view(np.uint64), want_view.view(np.uint64))
+    monkeypatch.setenv("PFMSCAN_UPLOAD_NO_PREAD", "1")        # the mapping itself as the source: the same bytes
+    _, got = ctx.scan_host(motif, None, mapped, want_seq=False)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    monkeypatch.delenv("PFMSCAN_UPLOAD_NO_PREAD")
+    del mapped, got
+    gc.collect()
+    assert len(ctx._mappings) == before                       # forgotten before the mapping went away
+    motif.close()
