@@ -99,6 +99,15 @@ def _guess_seq_type(args):
     sys.exit(1)
 
 
+def store_batches(minscore):
+    """batch length, in units of RNASCAN_BATCH_POSITIONS, of a scan whose profile rows are slices of a mapped store (nothing
+    is copied on the host, the chunked pipeline keeps the device scratch at two chunks): 32 with a finite threshold -- the
+    rows of a batch are its hits, and one long pipeline call has one ramp-up instead of one per batch -- 8 at `-m ' -inf'`,
+    where every window is a row and a batch also holds its score arrays"""
+    import math
+    return 32 if math.isfinite(float(minscore)) else 8
+
+
 def load_motif(pfm_file, pseudocount, letters, background):
     """rnascan.py:210-235 (same messages)."""
     motifs_set = {}
@@ -155,7 +164,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         df = shard.scan_sharded(ids, ps.lengths,
                                 lambda part: scanner.scan_store(engine, ps, pssm, args.minscore, args.pairing,
                                                                 part[0] if part else 0, part[-1] + 1 if part else 0, compact),
-                                rank, world, dist, max_positions=8 * shard.batch_positions(), sink=sink)
+                                rank, world, dist, max_positions=store_batches(args.minscore) * shard.batch_positions(), sink=sink)
         fasta.eprint("Processed %d sequences" % len(ps.ids))
         return df
     if os.path.isdir(source):
@@ -374,7 +383,7 @@ def main(argv=None, engine=None, out=None):
             # a packed store that holds the FASTA's records in the FASTA's order: every batch is a slice of the mapped file
             # plus its packed codes (1 byte per position) -- batches long enough for the chunked upload-beside-scan pipeline
             final = shard.scan_sharded(recs, recs.lengths, scan_pairs, rank, world, dist,
-                                       max_positions=(8 if same_order else 1) * shard.batch_positions(),
+                                       max_positions=(store_batches(args.minscore) if same_order else 1) * shard.batch_positions(),
                                        sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
         else:                                  # duplicate ids join across records: two whole tables + join
             named = load_many(list(where)) if ps is None else [t for sid in where for t in load(sid)]
