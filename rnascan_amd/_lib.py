@@ -478,7 +478,7 @@ class Context(object):
         pread the file and never touch the mapping (no page faults, nothing to unmap page by page at exit).  The range is
         forgotten again just before the memmap goes away."""
         import weakref
-        if mm is None or getattr(mm, "mode", "r") not in ("r", "c") or mm.nbytes == 0:
+        if mm is None or getattr(mm, "mode", None) != "r" or mm.nbytes == 0:      # "c": private changes are not in the file
             return
         known = self.__dict__.setdefault("_mappings", {})
         base = mm.ctypes.data
