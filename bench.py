@@ -257,6 +257,42 @@ def secondary_legs(torch, _lib, ctx, args, dev, codes, profile, ptype, n_pos, ou
                       "value": w8 / (ms * 1e-3), "unit": "windows/s", "hits_per_step": hits, "minscore_seq": 6.0,
                       "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
     m8.close()
+    # ---- SS hits: a structure letter-string PFM (7 letters, w = 12) at -m 6 over 100k x 3 kb structure strings, and the
+    # two-FASTA combined scan (sequence PFM AND structure-letter PFM, both at -m 6) over the two code streams
+    g = torch.Generator(device=dev)
+    g.manual_seed(20240601 + 77)
+    scodes = torch.randint(0, 7, (args.records, args.length + 1), dtype=torch.uint8, device=dev, generator=g)
+    scodes[:, args.length] = 7
+    scodes = scodes.view(-1)
+    t12, p12 = make_pssms(12, args.variant)
+    lt = np.full((12, 8), np.nan)
+    lt[:, :7] = p12
+    ms7, mq = ctx.motif(lt, None), ctx.motif(t12, None)
+    w12 = args.records * (args.length - 12 + 1)
+
+    def ss():
+        cnt.zero_()
+        ctx.hits_letters_f64_dev(ms7, scodes.data_ptr(), n_pos, 6.0, cap, hp.data_ptr(), ht.data_ptr(), cnt.data_ptr(), stream)
+    ms = timed(torch, ss, 20, 3)
+    hits = int(cnt.item())
+    gbs = (args.records * args.length + hits * 16) / (ms * 1e-3) / 1e9
+    out["ss_hits"] = {"workload": "SS hits: structure letter-string PFM (7 letters, w=12) at -m 6 over %d x %d structure strings, "
+                                  "fp64 compare and score, k_letters_cred8" % (args.records, args.length),
+                      "ms_per_step": ms, "steps": 20, "value": w12 / (ms * 1e-3), "unit": "windows/s", "hits_per_step": hits,
+                      "minscore": 6.0, "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                      "vs_c2_hits": ms / out["c2_hits"]["ms_per_step"]}
+
+    def pair():
+        cnt.zero_()
+        ctx.hits_pair_dev(mq, ms7, codes.data_ptr(), scodes.data_ptr(), n_pos, 6.0, 6.0, cap, hp.data_ptr(), hs.data_ptr(),
+                          ht.data_ptr(), cnt.data_ptr(), stream)
+    ms = timed(torch, pair, 10, 2)
+    out["rnass_two_fasta"] = {"workload": "two-FASTA RNASS: sequence PFM (w=12) AND structure letter-string PFM (w=12) at -m 6 over the "
+                                          "two code streams: letters pass + k_letters_at at its hits (incl. the count read-back)",
+                              "ms_per_step": ms, "steps": 10, "value": w12 / (ms * 1e-3), "unit": "windows/s",
+                              "hits_per_step": int(cnt.item()), "minscore": 6.0}
+    ms7.close()
+    mq.close()
     return out
 
 

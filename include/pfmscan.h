@@ -27,7 +27,12 @@
  *   Records are concatenated into one stream of n_pos positions; every record
  *   is followed by exactly ONE separator position whose code is PFMSCAN_SEP.
  *     codes    uint8 [n_pos]      letter index 0..6, or PFMSCAN_SEP (7) for a
- *                                 separator or any letter outside the alphabet
+ *                                 separator or any letter outside the alphabet.
+ *                                 Generic-alphabet scans (pfmscan_scan_letters_f64_*,
+ *                                 pfmscan_hits_letters_f64_*, the second stream of
+ *                                 pfmscan_hits_pair_*) read bits 0..2 only: the host may keep
+ *                                 the letter's CASE in bit 3 (structure strings are reported as
+ *                                 written, rnascan.py:186-197, :272)
  *     profile  float/double [n_pos][7] row-major averaged-structure profile
  *                                 (rnascan.py:296-297 after `del struct['PO']`),
  *                                 columns already paired with the PSSM's; the
@@ -47,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 5
+#define PFMSCAN_ABI_VERSION 6
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -211,6 +216,56 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                         int64_t *hit_pos, float *hit_seq, double *hit_struct,
                         int64_t *n_hits);
 
+/* ---- thresholded hits of a generic-alphabet letter scan, score in fp64 -------------------------
+ * (`rnascan -q pfm structs.fa`.)  Replaces `pm.search(seq, threshold=minscore)` (rnascan.py:263) over
+ * ExtendedPositionSpecificScoringMatrix._py_calculate (matrix.py:25-43) for an alphabet that is not a nucleotide
+ * alphabet: the score is the sequential fp64 sum (Python floats, NO float32 cast), an unknown letter makes the window
+ * NaN, hit <=> score > thr (strict: NaN and -inf never pass, not even at thr = -inf).  Letters-only motif, up to 7
+ * letters (codes 0..6).  Finite thresholds and widths up to 32 run an integer prefilter with one-sided rounding
+ * (k_letters_cred8) and the exact sum for its survivors; otherwise every window gets the exact sum.
+ *   d_hit_pos int64 [capacity], d_hit_score double [capacity]; d_hit_count: one uint64 the caller zeroes, afterwards
+ *   the TOTAL number of hits (only the first `capacity` are stored).  Hits in no particular order; asynchronous. */
+int pfmscan_hits_letters_f64_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                                 const uint8_t *d_codes, int64_t n_pos, double thr,
+                                 int64_t capacity, int64_t *d_hit_pos, double *d_hit_score,
+                                 uint64_t *d_hit_count, void *stream);
+/* Staged (pfmscan_stage with codes) and host-buffer forms: hits sorted by position, capacity protocol of
+ * pfmscan_hits_host. */
+int pfmscan_hits_letters_f64_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif, double thr,
+                                    int64_t capacity, int64_t *hit_pos, double *hit_score,
+                                    int64_t *n_hits);
+int pfmscan_hits_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
+                                  const uint8_t *codes, int64_t n_pos, double thr,
+                                  int64_t capacity, int64_t *hit_pos, double *hit_score,
+                                  int64_t *n_hits);
+
+/* ---- two code streams: sequence letters AND structure letters in one call --------------------
+ * (`rnascan -p pfm -q pfm seqs.fa structs.fa`, rnascan.py:119-123.)  Replaces the two scan_main passes and the
+ * inner join of combine() (rnascan.py:416-434): codes = the RNA stream scored by motif_seq as in pfmscan_hits_dev
+ * (float32 of the fp64 sum, _pwm.c:34-68), codes2 = the structure letters of the SAME records in the same layout
+ * (same offsets, separators at the same positions) scored by motif_struct as in pfmscan_hits_letters_f64_dev.
+ *   hit <=> seq(p) > thr_seq and struct(p) > thr_struct            (both strict)
+ * Both motifs are letters-only and share the width m (the join is on Start AND End).  The sequence letters pass runs
+ * over everything, the structure letters are read at its hits only (k_letters_at).  Synchronises `stream`.
+ * Hit arrays and count as in pfmscan_hits_dev (d_hit_struct = the fp64 structure score). */
+int pfmscan_hits_pair_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif_seq,
+                          const pfmscan_motif *motif_struct, const uint8_t *d_codes,
+                          const uint8_t *d_codes2, int64_t n_pos, double thr_seq,
+                          double thr_struct, int64_t capacity, int64_t *d_hit_pos,
+                          float *d_hit_seq, double *d_hit_struct, uint64_t *d_hit_count,
+                          void *stream);
+/* A second code stream beside the one staged by pfmscan_stage (same n_pos); forgotten by the next pfmscan_stage. */
+int pfmscan_stage_codes2(pfmscan_ctx *ctx, const uint8_t *codes2, int64_t n_pos);
+int pfmscan_hits_pair_staged(pfmscan_ctx *ctx, const pfmscan_motif *motif_seq,
+                             const pfmscan_motif *motif_struct, double thr_seq, double thr_struct,
+                             int64_t capacity, int64_t *hit_pos, float *hit_seq,
+                             double *hit_struct, int64_t *n_hits);
+int pfmscan_hits_pair_host(pfmscan_ctx *ctx, const pfmscan_motif *motif_seq,
+                           const pfmscan_motif *motif_struct, const uint8_t *codes,
+                           const uint8_t *codes2, int64_t n_pos, double thr_seq, double thr_struct,
+                           int64_t capacity, int64_t *hit_pos, float *hit_seq, double *hit_struct,
+                           int64_t *n_hits);
+
 /* ---- multi-PFM libraries: every motif in ONE pass (BASELINE config 5) ----------
  * The reference loads one PFM file per run (load_motif, rnascan.py:217-218), scans only the first
  * motif of its dict (rnascan.py:262) and would re-read every sequence and profile per motif,
@@ -362,8 +417,9 @@ int pfmscan_profile_parse(const char *buf, int64_t n, int n_cols, int64_t capaci
  *            blob[offsets[i] .. offsets[i + 1]) for i = index[r]  (record ids, descriptions, motif ids; the
  *            caller has applied csv quoting to the values)
  *   FIXED    data = bytes [n_rows][width], trailing NULs dropped (numpy 'S' arrays)
- *   WINDOW   data = int64 stream positions [n_rows], aux = the code stream, blob = 8 letters: the `width` letters
- *            blob[code & 7] of the window at each position (the Sequence column)
+ *   WINDOW   data = int64 stream positions [n_rows], aux = the code stream, blob = 16 letters: the `width` letters
+ *            blob[code & 15] of the window at each position (the Sequence column; codes 8..15 = the letters of codes
+ *            0..7 as the input wrote them in lower case, see "codes" above)
  *   SPAN     data = int64 index [n_rows], aux = int64 [n_values][2] (offset, length) into blob: row r holds those
  *            bytes of blob (ids / headers straight from the mapped FASTA), csv-quoted here when they hold a tab, a
  *            double quote or a line break
@@ -402,6 +458,11 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
  * next (0 at the start).  capacity >= n + 21 x (line ends in the block) always suffices; PFMSCAN_E_CAPACITY otherwise. */
 int pfmscan_tsv_number(const char *in, int64_t n, int64_t first_id, char *out, int64_t capacity,
                        int64_t *n_out, int64_t *n_rows, int *in_quotes);
+
+/* `round(score, 3)` of rnascan.py:273 for Python floats (the structure letter scores of matrix.py:25-43 are Python
+ * floats): out[i] = the double nearest to the decimal with `decimals` (0..15) digits after the point that is nearest
+ * to in[i]'s exact value, ties to even -- float.__round__, which numpy.round is not.  NaN / inf pass through. */
+int pfmscan_round_decimals(const double *in, int64_t n, int decimals, double *out, int n_threads);
 
 /* ---- measurement helper ------------------------------------------------------
  * Average device time in milliseconds of `iters` back-to-back pfmscan_scan_dev

@@ -22,7 +22,7 @@ NCODE = 8
 NSTRUCT = 7
 MAX_M = 64            # widest PFM of the tuned kernels and of PFM libraries
 MAX_WIDTH = 4096      # widest PFM accepted (wider than MAX_M: the plain rolled-loop kernel)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -35,6 +35,8 @@ SYMBOLS = [
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
     "pfmscan_debug_quad_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
+    "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
+    "pfmscan_hits_pair_dev", "pfmscan_stage_codes2", "pfmscan_hits_pair_staged", "pfmscan_hits_pair_host", "pfmscan_round_decimals",
     "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
@@ -133,6 +135,14 @@ def load():
     L.pfmscan_fasta_encode.argtypes = [vp, vp, vp, vp, i64, i64, vp, i32, vp, vp, i32]
     L.pfmscan_profile_parse.argtypes = [ctypes.c_char_p, i64, i32, i64, vp, ctypes.POINTER(i64)]
     L.pfmscan_tsv_number.argtypes = [vp, i64, i64, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]
+    L.pfmscan_hits_letters_f64_dev.argtypes = [vp, vp, vp, i64, dbl, i64, vp, vp, vp, vp]
+    L.pfmscan_hits_letters_f64_staged.argtypes = [vp, vp, dbl, i64, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_hits_letters_f64_host.argtypes = [vp, vp, vp, i64, dbl, i64, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_hits_pair_dev.argtypes = [vp, vp, vp, vp, vp, i64, dbl, dbl, i64, vp, vp, vp, vp, vp]
+    L.pfmscan_stage_codes2.argtypes = [vp, vp, i64]
+    L.pfmscan_hits_pair_staged.argtypes = [vp, vp, vp, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_hits_pair_host.argtypes = [vp, vp, vp, vp, vp, i64, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
+    L.pfmscan_round_decimals.argtypes = [vp, i64, i32, vp, i32]
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i32), i32]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
@@ -260,6 +270,19 @@ def profile_parse(data, n_cols):
     if rc != OK:
         _raise(L, None, rc)
     return out[:k.value]
+
+
+def round_decimals(values, decimals=3, threads=0):
+    """``[round(float(x), decimals) for x in values]`` as a float64 array: Python's float rounding (the nearest decimal
+    of the EXACT binary value, ties to even -- rnascan.py:273 applies it to every reported score), natively and in
+    parallel.  numpy.round is a different function (scale, rint, unscale) and differs from it near ties."""
+    L = load()
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    out = np.empty_like(a)
+    rc = L.pfmscan_round_decimals(_ptr(a), a.size, int(decimals), _ptr(out), int(threads))
+    if rc != OK:
+        _raise(L, None, rc)
+    return out
 
 
 TSV_MAX_PIECES = 16
@@ -552,6 +575,71 @@ class Context(object):
             self._check(rc, k.value)
             k = int(k.value)
             return pos[:k].copy(), (sq[:k].copy() if motif.has_letters else None), (st[:k].copy() if motif.has_struct else None)
+
+    # -- generic-alphabet letter hits in fp64; two code streams ---------------------------------
+    def hits_letters_f64_staged(self, motif, thr, capacity=None):
+        """hits of a letters-only motif over the staged codes, fp64 compare and score (matrix.py:25-43 + rnascan.py:263)
+        -> (pos int64[k] sorted, score float64[k])"""
+        n = int(self._L.pfmscan_staged_positions(self._h))
+        if n < 0:
+            raise ValueError("no stream staged (call stage first)")
+        cap = int(capacity) if capacity is not None else max(1024, n // 64)
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            sc = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_hits_letters_f64_staged(self._h, motif._h, float(thr), cap, _ptr(pos), _ptr(sc), ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
+            return pos[:k].copy(), sc[:k].copy()
+
+    def hits_letters_f64_host(self, motif, codes, thr, capacity=None):
+        self.stage(codes, None)
+        return self.hits_letters_f64_staged(motif, thr, capacity)
+
+    def stage_codes2(self, codes2):
+        """a second code stream (the structure letters of the staged records) beside the staged one"""
+        codes2 = np.ascontiguousarray(codes2, dtype=np.uint8)
+        self._check(self._L.pfmscan_stage_codes2(self._h, _ptr(codes2), codes2.size))
+
+    def hits_pair_staged(self, motif_seq, motif_struct, thr_seq, thr_struct, capacity=None):
+        """hits of (sequence letters AND structure letters) over the two staged code streams
+        -> (pos int64[k] sorted, seq float32[k], struct float64[k])"""
+        n = int(self._L.pfmscan_staged_positions(self._h))
+        if n < 0:
+            raise ValueError("no stream staged (call stage first)")
+        cap = int(capacity) if capacity is not None else max(1024, n // 64)
+        while True:
+            pos = np.empty(cap, dtype=np.int64)
+            sq = np.empty(cap, dtype=np.float32)
+            st = np.empty(cap, dtype=np.float64)
+            k = ctypes.c_int64(0)
+            rc = self._L.pfmscan_hits_pair_staged(self._h, motif_seq._h, motif_struct._h, float(thr_seq), float(thr_struct), cap,
+                                                  _ptr(pos), _ptr(sq), _ptr(st), ctypes.byref(k))
+            if rc == E_CAPACITY and capacity is None:
+                cap = int(k.value)
+                continue
+            self._check(rc, k.value)
+            k = int(k.value)
+            return pos[:k].copy(), sq[:k].copy(), st[:k].copy()
+
+    def hits_pair_host(self, motif_seq, motif_struct, codes, codes2, thr_seq, thr_struct, capacity=None):
+        self.stage(codes, None)
+        self.stage_codes2(codes2)
+        return self.hits_pair_staged(motif_seq, motif_struct, thr_seq, thr_struct, capacity)
+
+    def hits_letters_f64_dev(self, motif, d_codes, n_pos, thr, capacity, d_hit_pos, d_hit_score, d_hit_count, stream=None):
+        self._check(self._L.pfmscan_hits_letters_f64_dev(self._h, motif._h, _ptr(d_codes), int(n_pos), float(thr), int(capacity),
+                                                         _ptr(d_hit_pos), _ptr(d_hit_score), _ptr(d_hit_count), _ptr(stream)))
+
+    def hits_pair_dev(self, motif_seq, motif_struct, d_codes, d_codes2, n_pos, thr_seq, thr_struct, capacity,
+                      d_hit_pos, d_hit_seq, d_hit_struct, d_hit_count, stream=None):
+        self._check(self._L.pfmscan_hits_pair_dev(self._h, motif_seq._h, motif_struct._h, _ptr(d_codes), _ptr(d_codes2), int(n_pos),
+                                                  float(thr_seq), float(thr_struct), int(capacity), _ptr(d_hit_pos), _ptr(d_hit_seq),
+                                                  _ptr(d_hit_struct), _ptr(d_hit_count), _ptr(stream)))
 
     # -- multi-PFM libraries (every motif in one pass) --------------------------------
     def library(self, letter_tables, struct_pssms=None):

@@ -108,6 +108,30 @@ def store_batches(minscore):
     return 32 if math.isfinite(float(minscore)) else 8
 
 
+class _Zip(object):
+    """two sliceable record sequences of the same length, sliced together (shard.scan_sharded cuts batches with [a:b])"""
+
+    def __init__(self, first, second):
+        self.first, self.second = first, second
+
+    def __len__(self):
+        return len(self.first)
+
+    def __getitem__(self, key):
+        return self.first[key], self.second[key]
+
+
+def _same_records(seq_fasta, struct_fasta):
+    """(LazyFasta of the sequences, LazyFasta of the structures) when the two files hold the same record ids in the same
+    order, every id once -- the shape `rnascan seqs.fa structs.fa` is made for: record k of one file pairs with record k
+    of the other and a batch of the join is the join of a batch.  Otherwise None: the two tables are made and joined as the
+    reference does (rnascan.py:416-434)."""
+    recs, srecs = fasta.LazyFasta(seq_fasta), fasta.LazyFasta(struct_fasta)
+    ids = list(recs.ids)
+    ok = len(recs) == len(srecs) and len(recs) > 0 and ids == list(srecs.ids) and len(set(ids)) == len(ids)
+    return (recs, srecs) if ok else None
+
+
 def load_motif(pfm_file, pseudocount, letters, background):
     """rnascan.py:210-235 (same messages)."""
     motifs_set = {}
@@ -308,6 +332,9 @@ def main(argv=None, engine=None, out=None):
         return sink
 
     streaming = not args.testseq
+    pair_files = None
+    if seq_type == "RNASS" and not args.testseq and not os.path.isdir(seq_source) and not os.path.isdir(struct_source):
+        pair_files = _same_records(seq_source, struct_source)
     if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
         # sequence FASTA + averaged-structure directory (or packed store): one fused kernel pass per batch (configs 3, 5).
         # Only an index of both sides is held; a batch reads its own records and the profiles of those records.
@@ -396,6 +423,28 @@ def main(argv=None, engine=None, out=None):
                 rank, world, dist)
             if rank == 0:
                 final = scanner.combine(seq_results, struct_results)
+    elif pair_files is not None:
+        # sequence FASTA + structure FASTA holding the same records in the same order (rnascan.py:119-123): the letters of
+        # both files go to the device as two code streams and a row needs seq > m AND struct > m there (what combine()'s
+        # inner join of the two tables keeps, rnascan.py:416-434); rows are streamed batch by batch, no table is held.
+        recs, srecs = pair_files
+        fasta.eprint("Scanning sequences ")
+        fasta.eprint("Processed %d sequences" % len(recs))
+        fasta.eprint("Scanning sequences ")
+        fasta.eprint("Processed %d sequences" % len(srecs))
+
+        def scan_both(part):
+            a, b = part
+            df = scanner.scan_pair(eng, a, b, seq_pssm, struct_pssm, args.minscore, columns=streaming)
+            if df is None:                     # e.g. a record whose two strings differ in length: this batch's two tables, joined
+                df = scanner.combine(scanner.scan_records(eng, a, seq_pssm, fasta.RNA, args.minscore),
+                                     scanner.scan_records(eng, b, struct_pssm, fasta.STRUCT, args.minscore))
+                df = df[scanner.COMBINED_COLUMNS]
+            return df
+
+        final = shard.scan_sharded(_Zip(recs, srecs), recs.lengths, scan_both, rank, world, dist,
+                                   max_positions=8 * shard.batch_positions(),
+                                   sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
     else:
         one_table = streaming and seq_type in ("RNA", "SS")
         if seq_type in ("RNA", "RNASS"):

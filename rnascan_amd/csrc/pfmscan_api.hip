@@ -121,7 +121,7 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
                       &ctx->cand_count, &ctx->sort_keys_in, &ctx->sort_keys_out, &ctx->sort_vals_in, &ctx->sort_vals_out,
                       &ctx->sort_temp, &ctx->sort_seq, &ctx->sort_struct, &ctx->hit_motif, &ctx->sort_motif, &ctx->lib_pos,
                       &ctx->lib_motif, &ctx->lib_seq, &ctx->lib_struct, &ctx->lib_count, &ctx->pipe_codes[0], &ctx->pipe_codes[1],
-                      &ctx->pipe_profile[0], &ctx->pipe_profile[1]})
+                      &ctx->pipe_profile[0], &ctx->pipe_profile[1], &ctx->codes2})
         release(*b);
     upload_release(ctx);
     for (int i = 0; i < 2; ++i) {
@@ -171,6 +171,10 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
     if (letter_table) {
         e = hipMalloc((void **)&mo->d_letters, sizeof(double) * m * 8);
         if (e == hipSuccess) e = hipMemcpy(mo->d_letters, letter_table, sizeof(double) * m * 8, hipMemcpyHostToDevice);
+    }
+    if (letter_table && m <= 32) {
+        mo->h_letters = new (std::nothrow) double[(size_t)m * 8];
+        if (mo->h_letters) std::memcpy(mo->h_letters, letter_table, sizeof(double) * m * 8);
     }
     if (e == hipSuccess && letter_table) {
         // hits-mode prefilter table: only when the alphabet is the 4 codes 0..3 (columns 4..7 all NaN)
@@ -237,6 +241,7 @@ void pfmscan_motif_destroy(pfmscan_motif *mo)
     if (mo->d_struct) (void)hipFree(mo->d_struct);
     if (mo->d_quad) (void)hipFree(mo->d_quad);
     delete[] mo->h_quadsum;
+    delete[] mo->h_letters;
     delete mo;
 }
 
@@ -269,6 +274,8 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.d_quad = mo->d_quad;
     a.quad_thr = &mo->quad_thr;
     a.cred_cache = &mo->cred_cache;
+    a.h_letters = mo->h_letters;
+    a.cred8_cache = &mo->cred8_cache;
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;
@@ -288,7 +295,7 @@ int pfmscan::do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream)
 // The ctx-owned sharded hit buffers (HIT_SHARDS regions of shard_cap slots, counters in ctx->count) -> the caller's host
 // arrays, sorted by position: capacity check, device sort (pfmscan_sort.hip), three contiguous copies.  Synchronises
 // ctx->stream.  Hit positions lie in [0, n_pos).
-int pfmscan::finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64_t n_pos, int64_t capacity, int64_t shard_cap,
+int pfmscan::finish_sorted_hits(pfmscan_ctx *ctx, bool has_seq, bool has_struct, int64_t n_pos, int64_t capacity, int64_t shard_cap,
                                 int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
 {
     int rc;
@@ -322,8 +329,8 @@ int pfmscan::finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64
     if ((rc = ensure(ctx, ctx->sort_struct, total * 8))) return rc;
     GatherArgs g;
     g.hit_pos = (const int64_t *)ctx->hit_pos.p;
-    g.hit_seq = mo->d_letters ? (const float *)ctx->hit_seq.p : nullptr;
-    g.hit_struct = mo->d_struct ? (const double *)ctx->hit_struct.p : nullptr;
+    g.hit_seq = has_seq ? (const float *)ctx->hit_seq.p : nullptr;
+    g.hit_struct = has_struct ? (const double *)ctx->hit_struct.p : nullptr;
     g.counts = (const unsigned long long *)ctx->count.p;
     g.shards = HIT_SHARDS;
     g.shard_cap = shard_cap;
@@ -342,11 +349,11 @@ int pfmscan::finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64
         if (e != hipSuccess) return fail_hip(ctx, e, "gather + sort of the hits");
     }
     HIP_TRY(ctx, hipMemcpyAsync(hit_pos, g.keys_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (hit_seq && mo->d_letters) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (hit_struct && mo->d_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_seq && has_seq) HIP_TRY(ctx, hipMemcpyAsync(hit_seq, g.seq_out, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_struct && has_struct) HIP_TRY(ctx, hipMemcpyAsync(hit_struct, g.struct_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (hit_seq && !mo->d_letters) std::fill(hit_seq, hit_seq + total, NAN);
-    if (hit_struct && !mo->d_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
+    if (hit_seq && !has_seq) std::fill(hit_seq, hit_seq + total, NAN);
+    if (hit_struct && !has_struct) std::fill(hit_struct, hit_struct + total, (double)NAN);
     return PFMSCAN_OK;
 }
 
@@ -545,6 +552,7 @@ int pfmscan_stage(pfmscan_ctx *ctx, const uint8_t *codes, const void *profile, i
     ctx->staged_dtype = profile ? profile_dtype : PFMSCAN_PROFILE_NONE;
     ctx->staged_codes = codes != nullptr;
     ctx->staged_profile = profile != nullptr;
+    ctx->staged_codes2 = false;
     return PFMSCAN_OK;
 }
 
@@ -640,7 +648,8 @@ int pfmscan_hits_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, double thr_se
     HitSink sink = {(int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p, (double *)ctx->hit_struct.p,
                     (unsigned long long *)ctx->count.p, HIT_SHARDS, shard_cap};
     if ((rc = hits_core(ctx, mo, a, thr_seq, thr_struct, sink, ctx->stream, true))) return rc;
-    return finish_sorted_hits(ctx, mo, n_pos, capacity, shard_cap, hit_pos, hit_seq, hit_struct, n_hits);
+    return finish_sorted_hits(ctx, mo->d_letters != nullptr, mo->d_struct != nullptr, n_pos, capacity, shard_cap, hit_pos, hit_seq,
+                              hit_struct, n_hits);
 }
 
 int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, const void *profile,
@@ -656,6 +665,224 @@ int pfmscan_hits_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *
     int rc = pfmscan_stage(ctx, mo->d_letters ? codes : nullptr, mo->d_struct ? profile : nullptr, profile_dtype, n_pos);
     if (rc) return rc;
     return pfmscan_hits_staged(ctx, mo, thr_seq, thr_struct, capacity, hit_pos, hit_seq, hit_struct, n_hits);
+}
+
+// ---- generic-alphabet letter hits in fp64 (structure letter strings: SURVEY 8f N4) ---------------------------
+static int fill_f64_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, int64_t n_pos, double thr, ScanArgs &a)
+{
+    int rc = check_and_fill(ctx, mo, d_codes, nullptr, PFMSCAN_PROFILE_NONE, n_pos, a);
+    if (rc) return rc;
+    if (!mo->d_letters) return fail(ctx, PFMSCAN_E_BADARG, "motif has no letter table");
+    if (std::isnan(thr)) return fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
+    a.struct_pssm = nullptr;
+    a.profile = nullptr;
+    a.hits = 1;
+    a.f64_hits = 1;
+    a.thr_seq = thr;
+    a.thr_struct = -INFINITY;
+    return PFMSCAN_OK;
+}
+
+int pfmscan_hits_letters_f64_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, int64_t n_pos, double thr,
+                                 int64_t capacity, int64_t *d_hit_pos, double *d_hit_score, uint64_t *d_hit_count, void *stream)
+{
+    ScanArgs a;
+    int rc = fill_f64_hits(ctx, mo, d_codes, n_pos, thr, a);
+    if (rc) return rc;
+    if (capacity < 0 || !d_hit_count || (capacity > 0 && !d_hit_pos)) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_hits_letters_f64_dev: bad hit buffers");
+    a.capacity = capacity;
+    a.hit_pos = d_hit_pos;
+    a.hit_seq = nullptr;
+    a.hit_struct = d_hit_score;
+    a.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
+    a.hit_shards = 1;
+    return do_launch(ctx, a, stream);
+}
+
+int pfmscan_hits_letters_f64_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo, double thr, int64_t capacity, int64_t *hit_pos,
+                                    double *hit_score, int64_t *n_hits)
+{
+    if (!n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    int rc = check_staged(ctx, mo);
+    if (rc) return rc;
+    if (!mo->d_letters) return fail(ctx, PFMSCAN_E_BADARG, "motif has no letter table");
+    if (capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    const int64_t n_pos = ctx->staged_n;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (capacity > 0 && !hit_pos) return fail(ctx, PFMSCAN_E_BADARG, "hit_pos is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t shard_cap = std::max<int64_t>(std::min<int64_t>(capacity, capacity / HIT_SHARDS * 2 + 4096), 1);
+    const size_t slots = (size_t)shard_cap * HIT_SHARDS;
+    const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
+    if ((rc = ensure(ctx, ctx->hit_pos, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_struct, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->count, counter_bytes))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->count.p, 0, counter_bytes, ctx->stream));
+    ScanArgs a;
+    if ((rc = fill_f64_hits(ctx, mo, (const uint8_t *)ctx->codes.p, n_pos, thr, a))) return rc;
+    a.capacity = shard_cap;
+    a.hit_pos = (int64_t *)ctx->hit_pos.p;
+    a.hit_seq = nullptr;
+    a.hit_struct = (double *)ctx->hit_struct.p;
+    a.hit_count = (unsigned long long *)ctx->count.p;
+    a.hit_shards = HIT_SHARDS;
+    if ((rc = do_launch(ctx, a, ctx->stream))) return rc;
+    return finish_sorted_hits(ctx, false, true, n_pos, capacity, shard_cap, hit_pos, nullptr, hit_score, n_hits);
+}
+
+int pfmscan_hits_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *codes, int64_t n_pos, double thr,
+                                  int64_t capacity, int64_t *hit_pos, double *hit_score, int64_t *n_hits)
+{
+    if (!ctx || !mo || !n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (n_pos < 0 || capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (!codes) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    int rc = pfmscan_stage(ctx, codes, nullptr, PFMSCAN_PROFILE_NONE, n_pos);
+    if (rc) return rc;
+    return pfmscan_hits_letters_f64_staged(ctx, mo, thr, capacity, hit_pos, hit_score, n_hits);
+}
+
+// ---- two code streams: sequence letters AND structure letters (two-FASTA RNASS mode) ---------------------------
+// Phase 1: the sequence letters pass over everything (any of the letters hits kernels) -> candidates in the ctx's
+// candidate buffers; phase 2: k_letters_at scores the structure letters at the candidates only.  The candidate buffers
+// start at 1/32 of the windows; a denser threshold is retried once with the exact sizes the counters reported.
+static int pair_core(pfmscan_ctx *ctx, const pfmscan_motif *mo_seq, const pfmscan_motif *mo_st, const uint8_t *d_codes,
+                     const uint8_t *d_codes2, int64_t n_pos, double thr_seq, double thr_struct, const HitSink &sink, hipStream_t st)
+{
+    int rc;
+    ScanArgs a1, a2;
+    if ((rc = check_and_fill(ctx, mo_seq, d_codes, nullptr, PFMSCAN_PROFILE_NONE, n_pos, a1))) return rc;
+    if ((rc = check_and_fill(ctx, mo_st, d_codes2, nullptr, PFMSCAN_PROFILE_NONE, n_pos, a2))) return rc;
+    a1.struct_pssm = a2.struct_pssm = nullptr;
+    a1.profile = a2.profile = nullptr;
+    const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
+    if ((rc = ensure(ctx, ctx->cand_count, counter_bytes))) return rc;
+    std::vector<unsigned long long> counters((size_t)HIT_SHARDS * HIT_COUNTER_STRIDE);
+    pfmscan_motif letters_only = *mo_seq;
+    letters_only.d_struct = nullptr;
+    int64_t cand_shard_cap = std::max<int64_t>(n_pos / 32 / HIT_SHARDS * 2 + 4096, 1);
+    uint64_t n_cand = 0, worst = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const size_t cand_slots = (size_t)cand_shard_cap * HIT_SHARDS;
+        if ((rc = ensure(ctx, ctx->cand_pos, cand_slots * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->cand_seq, cand_slots * 4))) return rc;
+        HitSink cs = {(int64_t *)ctx->cand_pos.p, (float *)ctx->cand_seq.p, nullptr, (unsigned long long *)ctx->cand_count.p,
+                      HIT_SHARDS, cand_shard_cap};
+        ScanArgs p1 = a1;
+        fill_sink(p1, &letters_only, cs, thr_seq, -INFINITY);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cand_count.p, 0, counter_bytes, st));
+        if ((rc = do_launch(ctx, p1, st))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(counters.data(), ctx->cand_count.p, counter_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        n_cand = worst = 0;
+        for (int s = 0; s < HIT_SHARDS; ++s) {
+            n_cand += counters[(size_t)s * HIT_COUNTER_STRIDE];
+            worst = std::max<uint64_t>(worst, counters[(size_t)s * HIT_COUNTER_STRIDE]);
+        }
+        if ((int64_t)worst <= cand_shard_cap) break;
+        if (attempt == 1) return fail(ctx, PFMSCAN_E_HIP, "candidate counts changed between two identical passes");
+        cand_shard_cap = (int64_t)worst;                    // the same pass again, every shard sized for what it reported
+    }
+    if (n_cand == 0) return PFMSCAN_OK;
+    pfmscan_motif both = *mo_seq;                          // fill_sink: which hit arrays exist
+    both.d_struct = mo_st->d_letters;
+    fill_sink(a2, &both, sink, thr_seq, thr_struct);
+    hipError_t e = launch_letters_at(a2, (const int64_t *)ctx->cand_pos.p, (const float *)ctx->cand_seq.p,
+                                     (const unsigned long long *)ctx->cand_count.p, HIT_SHARDS, cand_shard_cap, st);
+    if (e != hipSuccess) return fail_hip(ctx, e, "launch k_letters_at");
+    return PFMSCAN_OK;
+}
+
+static int check_pair(pfmscan_ctx *ctx, const pfmscan_motif *mo_seq, const pfmscan_motif *mo_st, double thr_seq, double thr_struct)
+{
+    if (!ctx || !mo_seq || !mo_st) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or motif");
+    if (mo_seq->ctx != ctx || mo_st->ctx != ctx) return fail(ctx, PFMSCAN_E_BADARG, "motif belongs to another ctx");
+    if (!mo_seq->d_letters || !mo_st->d_letters) return fail(ctx, PFMSCAN_E_BADARG, "both motifs need a letter table");
+    if (mo_seq->m != mo_st->m)
+        return fail(ctx, PFMSCAN_E_BADSHAPE, "sequence and structure PFMs must have the same width for a combined scan");
+    if (std::isnan(thr_seq) || std::isnan(thr_struct)) return fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
+    return PFMSCAN_OK;
+}
+
+int pfmscan_hits_pair_dev(pfmscan_ctx *ctx, const pfmscan_motif *mo_seq, const pfmscan_motif *mo_st, const uint8_t *d_codes,
+                          const uint8_t *d_codes2, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
+                          int64_t *d_hit_pos, float *d_hit_seq, double *d_hit_struct, uint64_t *d_hit_count, void *stream)
+{
+    int rc = check_pair(ctx, mo_seq, mo_st, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (n_pos < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
+    if (capacity < 0 || !d_hit_count || (capacity > 0 && !d_hit_pos)) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_hits_pair_dev: bad hit buffers");
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (!d_codes || !d_codes2) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HitSink sink = {d_hit_pos, d_hit_seq, d_hit_struct, reinterpret_cast<unsigned long long *>(d_hit_count), 1, capacity};
+    return pair_core(ctx, mo_seq, mo_st, d_codes, d_codes2, n_pos, thr_seq, thr_struct, sink, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int pfmscan_stage_codes2(pfmscan_ctx *ctx, const uint8_t *codes2, int64_t n_pos)
+{
+    if (!ctx) return fail(ctx, PFMSCAN_E_BADARG, "NULL ctx");
+    if (ctx->staged_n < 0 || !ctx->staged_codes) return fail(ctx, PFMSCAN_E_BADARG, "no code stream staged (call pfmscan_stage first)");
+    if (n_pos != ctx->staged_n) return fail(ctx, PFMSCAN_E_BADARG, "the second code stream must have the staged stream's length");
+    ctx->staged_codes2 = false;
+    if (n_pos > 0) {
+        if (!codes2) return fail(ctx, PFMSCAN_E_BADARG, "codes2 is NULL");
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int rc = ensure(ctx, ctx->codes2, (size_t)n_pos);
+        if (rc) return rc;
+        if ((rc = upload(ctx, ctx->codes2.p, codes2, (size_t)n_pos, ctx->stream))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->staged_codes2 = true;
+    return PFMSCAN_OK;
+}
+
+int pfmscan_hits_pair_staged(pfmscan_ctx *ctx, const pfmscan_motif *mo_seq, const pfmscan_motif *mo_st, double thr_seq,
+                             double thr_struct, int64_t capacity, int64_t *hit_pos, float *hit_seq, double *hit_struct,
+                             int64_t *n_hits)
+{
+    if (!n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    int rc = check_pair(ctx, mo_seq, mo_st, thr_seq, thr_struct);
+    if (rc) return rc;
+    if (ctx->staged_n < 0 || !ctx->staged_codes || !ctx->staged_codes2)
+        return fail(ctx, PFMSCAN_E_BADARG, "two code streams must be staged (pfmscan_stage + pfmscan_stage_codes2)");
+    if (capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    const int64_t n_pos = ctx->staged_n;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (capacity > 0 && !hit_pos) return fail(ctx, PFMSCAN_E_BADARG, "hit_pos is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t shard_cap = std::max<int64_t>(std::min<int64_t>(capacity, capacity / HIT_SHARDS * 2 + 4096), 1);
+    const size_t slots = (size_t)shard_cap * HIT_SHARDS;
+    const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
+    if ((rc = ensure(ctx, ctx->hit_pos, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_seq, slots * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->hit_struct, slots * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->count, counter_bytes))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->count.p, 0, counter_bytes, ctx->stream));
+    HitSink sink = {(int64_t *)ctx->hit_pos.p, (float *)ctx->hit_seq.p, (double *)ctx->hit_struct.p,
+                    (unsigned long long *)ctx->count.p, HIT_SHARDS, shard_cap};
+    if ((rc = pair_core(ctx, mo_seq, mo_st, (const uint8_t *)ctx->codes.p, (const uint8_t *)ctx->codes2.p, n_pos, thr_seq, thr_struct,
+                        sink, ctx->stream)))
+        return rc;
+    return finish_sorted_hits(ctx, true, true, n_pos, capacity, shard_cap, hit_pos, hit_seq, hit_struct, n_hits);
+}
+
+int pfmscan_hits_pair_host(pfmscan_ctx *ctx, const pfmscan_motif *mo_seq, const pfmscan_motif *mo_st, const uint8_t *codes,
+                           const uint8_t *codes2, int64_t n_pos, double thr_seq, double thr_struct, int64_t capacity,
+                           int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    if (!ctx || !mo_seq || !mo_st || !n_hits) return fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (n_pos < 0 || capacity < 0) return fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (!codes || !codes2) return fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    int rc = pfmscan_stage(ctx, codes, nullptr, PFMSCAN_PROFILE_NONE, n_pos);
+    if (rc) return rc;
+    if ((rc = pfmscan_stage_codes2(ctx, codes2, n_pos))) return rc;
+    return pfmscan_hits_pair_staged(ctx, mo_seq, mo_st, thr_seq, thr_struct, capacity, hit_pos, hit_seq, hit_struct, n_hits);
 }
 
 // ---- the reference's native entry point ------------------------------------------

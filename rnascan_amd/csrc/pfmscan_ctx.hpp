@@ -16,6 +16,8 @@ struct pfmscan_motif {
     uint32_t *d_quad = nullptr;    // device: the credit table of the threshold quad_thr (rebuilt when the threshold changes)
     mutable double quad_thr = __builtin_nan("");
     mutable pfmscan::CredCache cred_cache;
+    double *h_letters = nullptr;   // host copy of the letter table [m][8] (m <= 32): operand of k_letters_cred8's credits
+    mutable pfmscan::Cred8Cache cred8_cache;
     double *d_struct = nullptr;    // [m][7]
     int m = 0;
     int struct_finite = 0;
@@ -39,6 +41,7 @@ struct pfmscan_ctx {
     int n_cu = 0;
     int64_t hbm = 0;
     char name[128] = {0};
+    DevBuf codes2;                              // second code stream of the two-FASTA combined scan (pfmscan_stage_codes2)
     DevBuf codes, profile, out_seq, out_struct, hit_pos, hit_seq, hit_struct, count, table;
     DevBuf cand_pos, cand_seq, cand_count;      // candidates of the two-phase combined scan
     DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, sort_seq, sort_struct;   // pfmscan_sort.hip
@@ -61,7 +64,7 @@ struct pfmscan_ctx {
     // staged stream (pfmscan_stage)
     int64_t staged_n = -1;
     int staged_dtype = PFMSCAN_PROFILE_NONE;
-    bool staged_codes = false, staged_profile = false;
+    bool staged_codes = false, staged_profile = false, staged_codes2 = false;
     // candidate-then-verify: the last full letters pass was selective -> skip the pilot next time
     bool two_phase_hot = false;
 };
@@ -76,7 +79,7 @@ void release(DevBuf &b);
 int check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uint8_t *d_codes, const void *d_profile, int profile_dtype,
                    int64_t n_pos, ScanArgs &a);
 int do_launch(pfmscan_ctx *ctx, const ScanArgs &a, void *stream);
-int finish_sorted_hits(pfmscan_ctx *ctx, const pfmscan_motif *mo, int64_t n_pos, int64_t capacity, int64_t shard_cap,
+int finish_sorted_hits(pfmscan_ctx *ctx, bool has_seq, bool has_struct, int64_t n_pos, int64_t capacity, int64_t shard_cap,
                        int64_t *hit_pos, float *hit_seq, double *hit_struct, int64_t *n_hits);
 // pfmscan_upload.hip: asynchronous host -> device copy on `st`; the source may be reused when it returns
 int upload(pfmscan_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t st);

@@ -8,6 +8,7 @@
 #include <charconv>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -592,7 +593,7 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
                 default: {                                           // PFMSCAN_TSV_WINDOW
                     const uint8_t *codes = static_cast<const uint8_t *>(col.aux) + static_cast<const int64_t *>(col.data)[r];
                     const char *letters = static_cast<const char *>(col.blob);
-                    for (int64_t j = 0; j < col.width; ++j) *p++ = letters[codes[j] & 7];
+                    for (int64_t j = 0; j < col.width; ++j) *p++ = letters[codes[j] & 15];
                     break;
                 }
                 }
@@ -611,6 +612,41 @@ int pfmscan_tsv_format(const pfmscan_tsv_column *cols, int n_cols, int64_t n_row
         pieces[2 * t + 1] = used[(size_t)t];
     }
     *n_pieces = threads;
+    return PFMSCAN_OK;
+}
+
+// round(x, decimals) of Python floats (rnascan.py:273 rounds every reported score to 3 places): the decimal string with
+// `decimals` digits after the point that is NEAREST to the exact binary value (ties to even), read back as a double --
+// float.__round__ does it through dtoa / strtod.  numpy.round (x * 10^d -> rint -> / 10^d) differs from it near ties.
+// Fast path: y = x * 10^d is within half an ulp of the exact product, so when y is clear of a tie by more than that the
+// integer r = rint(y) is the exact product's rounding too, and r / 10^d (ONE correctly rounded division of two exact
+// integers) is the double nearest to the decimal.  Only values within a few ulps of a tie take the string route.
+int pfmscan_round_decimals(const double *in, int64_t n, int decimals, double *out, int n_threads)
+{
+    if (n < 0 || (n > 0 && (!in || !out)) || decimals < 0 || decimals > 15) return fail(nullptr, PFMSCAN_E_BADARG, "pfmscan_round_decimals: bad argument");
+    double scale = 1.0;
+    for (int i = 0; i < decimals; ++i) scale *= 10.0;
+    parallel_ranges(n, pick_threads(n_threads, n >> 16), [&](int, int64_t a, int64_t b) {
+        char buf[400];
+        for (int64_t i = a; i < b; ++i) {
+            const double x = in[i];
+            if (!std::isfinite(x)) {
+                out[i] = x;
+                continue;
+            }
+            const double y = x * scale;
+            const double r = std::nearbyint(y);
+            const double slack = 0.5 - std::fabs(y - r);
+            if (std::fabs(y) < 0x1p51 && slack > std::fabs(y) * 0x1p-50) {
+                out[i] = r / scale;
+            } else if (std::fabs(y) >= 0x1p52) {
+                out[i] = x;                                         // no fractional digits left to drop (decimals <= 15)
+            } else {
+                std::snprintf(buf, sizeof buf, "%.*f", decimals, x);
+                out[i] = std::strtod(buf, nullptr);
+            }
+        }
+    });
     return PFMSCAN_OK;
 }
 

@@ -16,6 +16,13 @@ struct CredCache {
     uint16_t cr[16 * 16];
 };
 
+// the same for launch_letters_cred8 (pfmscan_letters8.hip): single-letter credits of an 8-code alphabet, up to 32 rows
+struct Cred8Cache {
+    double thr = __builtin_nan("");
+    int mode = 0;                // 1: k_letters_cred8 with cr; 2: dense threshold -> the exact kernel; 3: no integer prefilter possible
+    uint16_t cr[32 * 8];
+};
+
 struct ScanArgs {
     const uint8_t *codes;        // [n_pos] device, may be null when the motif has no letter table
     const void *profile;         // [n_pos][7] float or double, device, may be null
@@ -33,6 +40,8 @@ struct ScanArgs {
     uint32_t *d_quad;            // DEVICE: room for that table (256 entries of up to 16 bytes), owned by the motif
     double *quad_thr;            // HOST: the threshold d_quad currently holds credits for (NaN: none), owned by the motif
     CredCache *cred_cache;       // HOST: owned by the motif
+    const double *h_letters;     // HOST: the letter table [m][8] (operand of the single-letter credits of k_letters_cred8)
+    Cred8Cache *cred8_cache;     // HOST: owned by the motif
     const double *struct_pssm;   // [m][7] device or null
     int m;
     int struct_finite;           // every struct_pssm cell finite -> fast path legal
@@ -42,6 +51,8 @@ struct ScanArgs {
     double *out_letters_f64;     // letter scan with fp64 output (matrix.py:25-43)
     // hits mode
     int hits;
+    int f64_hits;                // letters-only hits of a generic alphabet (matrix.py:25-43): the fp64 sum itself is compared with
+                                 // thr_seq (no float32 cast) and reported in hit_struct
     double thr_seq, thr_struct;
     int64_t capacity;
     int64_t *hit_pos;
@@ -76,6 +87,12 @@ struct Tuning {
 };
 
 hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, const char **what);
+// pfmscan_letters8.hip: fp64 letter hits through the single-letter integer prefilter (false: not applicable, take the exact
+// kernel); fp64 letter score of a SECOND code stream at the candidates of a letters pass (two-FASTA combined scan)
+bool launch_letters_cred8(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err);
+hipError_t launch_letters_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
+                             const unsigned long long *cand_count, int cand_shards, int64_t cand_shard_cap,
+                             hipStream_t stream);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting of a kernel: `done` (one per kernel
 // instantiation) keeps one bit per device, so a second ctx on another device of the same process gets its attribute

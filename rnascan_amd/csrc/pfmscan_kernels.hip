@@ -53,130 +53,10 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
-#include "pfmscan_internal.hpp"
+#include "pfmscan_device.hpp"
 
 namespace pfmscan {
 
-constexpr int BLOCK = 256;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-// k_letters: a workgroup scores ITERS x 1024 windows (fewer for the widest PFM bucket, whose
-// code registers would otherwise spill)
-__host__ __device__ constexpr int let_iters(int ndw) { return ndw > 9 ? 2 : 4; }   // 8 rounds measured slower (occupancy 5)
-__host__ __device__ constexpr int let_tile(int ndw) { return BLOCK * 4 * let_iters(ndw); }
-
-// numpy.nan_to_num defaults (rnascan.py:306): NaN -> 0, +-inf -> +-DBL_MAX.
-__device__ __forceinline__ double nan_to_num(double d)
-{
-    double c = fmin(fmax(d, -DBL_MAX), DBL_MAX);
-    return (d != d) ? 0.0 : c;
-}
-
-// 4 code bytes at stream position p (p % 4 == 0); positions >= n_pos read as SEP.
-__device__ __forceinline__ uint32_t load_codes4(const uint8_t *__restrict__ codes, int64_t p, int64_t n_pos)
-{
-    if (p + 4 <= n_pos) return *reinterpret_cast<const uint32_t *>(codes + p);
-    uint32_t w = 0x07070707u;
-    if (p < n_pos) {
-        for (int b = 0; b < 4; ++b)
-            if (p + b < n_pos) w = (w & ~(0xFFu << (8 * b))) | ((uint32_t)codes[p + b] << (8 * b));
-    }
-    return w;
-}
-
-// A tile's codes (TILE window starts + CODE_HALO bytes of look-ahead) as 16-byte vectors: global -> registers
-// (fetch_codes, issued early) -> LDS (park_codes).  Every thread then reads its own 8-byte-strided
-// dwords from LDS.  Loading them straight from global -- each thread its 6..7 overlapping dwords,
-// every cache line requested 7 times, a 64-bit bounds test per dword -- was HALF of k_letters' time.
-constexpr int CODE_HALO = 80;                         // >= W - 1 + PFMSCAN_MAX_M + 1, multiple of 16
-template <int TILE> struct CodeStage {
-    static constexpr int NVEC = (TILE + CODE_HALO) / 16;
-    static constexpr int PER = (NVEC + BLOCK - 1) / BLOCK;
-    u32x4 r[PER];
-    __device__ __forceinline__ void fetch(const uint8_t *__restrict__ codes, int64_t tile0, int64_t n_pos)
-    {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * BLOCK;
-            const int64_t p = tile0 + 16 * (int64_t)i;
-            u32x4 v = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
-            if (i < NVEC) {
-                if (p + 16 <= n_pos) {
-                    v = *reinterpret_cast<const u32x4 *>(codes + p);
-                } else if (p < n_pos) {
-                    uint32_t t[4] = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
-                    for (int b = 0; b < 16; ++b)
-                        if (p + b < n_pos) t[b >> 2] = (t[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)codes[p + b] << (8 * (b & 3)));
-                    v = u32x4{t[0], t[1], t[2], t[3]};
-                }
-            }
-            r[k] = v;
-        }
-    }
-    __device__ __forceinline__ void park(uint8_t *cbuf) const
-    {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * BLOCK;
-            if (i < NVEC) *reinterpret_cast<u32x4 *>(cbuf + 16 * i) = r[k];
-        }
-    }
-};
-
-// Append the hits of one workgroup: every thread brings N windows.  Counts are
-// scanned inside the wave (shuffles) and across the 4 waves (LDS), then ONE returning
-// atomic per workgroup reserves the slots -- and none at all when the workgroup has no
-// hit, the usual case at real thresholds.  (One atomic per wave-instruction saturated
-// the counter word at percent-level hit rates: 9 ms on C2.)  Must be called by all 256
-// threads of the workgroup.  Hits of a workgroup land in position order; workgroups land
-// in arrival order (the host sorts).
-template <int N, typename PosF, typename SeqF, typename StF>
-__device__ __forceinline__ void emit_hits_block(const uint32_t passmask, PosF pos_of, SeqF seq_of, StF st_of, const ScanArgs &a)
-{
-    __shared__ unsigned long long hb_base;
-    __shared__ int hb_wave[BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt = __popc(passmask);
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(incl, d);
-        if (lane >= d) incl += y;
-    }
-    if (lane == 63) hb_wave[wave] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) {
-            const int t = hb_wave[w];
-            hb_wave[w] = run;
-            run += t;
-        }
-        // sharded counters spread the returning atomics over several words (one word saturates
-        // at ~88 atomics/us: 73k workgroups with hits cost 0.8 ms on a single counter)
-        const int sh = blockIdx.x & (a.hit_shards - 1);
-        hb_base = run ? atomicAdd(a.hit_count + sh * HIT_COUNTER_STRIDE, (unsigned long long)run) : 0ull;
-    }
-    __syncthreads();
-    if (passmask) {
-        unsigned long long slot = hb_base + (unsigned long long)(hb_wave[wave] + incl - cnt);
-        const unsigned long long off = (unsigned long long)(blockIdx.x & (a.hit_shards - 1)) * (unsigned long long)a.capacity;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (passmask & (1u << i)) {
-                if ((int64_t)slot < a.capacity) {                 // capacity is per shard
-                    a.hit_pos[off + slot] = pos_of(i) + a.pos_offset;
-                    if (a.hit_seq) a.hit_seq[off + slot] = seq_of(i);
-                    if (a.hit_struct) a.hit_struct[off + slot] = st_of(i);
-                }
-                ++slot;
-            }
-        }
-    }
-    __syncthreads();                                   // hb_* may be reused by the next call
-}
 
 // ---------------------------------------------------------------------------
 // k_letters: letter table only.  NDW = dwords of codes a thread may need:
@@ -350,7 +230,6 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 // scoring).  A wave whose queue cannot take the survivors of the next 64 windows flushes alone
 // (dense thresholds only).  Hits land in no particular order; the host sorts.
 // ---------------------------------------------------------------------------
-constexpr int WQ_CAP = 256;                           // hits a wave can park
 
 template <int NDW>
 __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
@@ -541,7 +420,6 @@ __global__ __launch_bounds__(BLOCK) void k_letters_pre(const ScanArgs a)
 struct CredTable {
     uint32_t d[16][8];                                // [letter pair c0 | c1 << 2][row pair j]
 };
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int NJ> struct CredEntry { typedef u32x4 type; };          // 3 or 4 row pairs: 16-byte entries; 5..8: two of them
 template <> struct CredEntry<2> { typedef u32x2 type; };
 template <> struct CredEntry<1> { typedef uint32_t type; };
@@ -1520,7 +1398,7 @@ static int walk_tiles(int64_t ntiles, const Tuning &t)
 // false when the motif has +inf / NaN two-letter sums (the fp32 prefilter handles those)
 static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
-    if (!(a.hits && a.pair_table && a.h_pairsum && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
+    if (!(a.hits && !a.f64_hits && a.pair_table && a.h_pairsum && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
     constexpr int CRED_TILE = BLOCK * 16;              // k_letters_cred: 16 windows per lane
     const int npair = (a.m + 1) / 2, nj = (npair + 1) / 2;
     CredCache local, *cc = a.cred_cache ? a.cred_cache : &local;
@@ -1585,7 +1463,7 @@ static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t 
 // device with the motif; it is rebuilt only when the threshold changes
 static bool launch_letters_quad(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
-    if (!(a.hits && a.pair_table && a.h_quadsum && a.d_quad && a.quad_thr && a.m <= 32 && t.credits && t.quad && std::isfinite(a.thr_seq)))
+    if (!(a.hits && !a.f64_hits && a.pair_table && a.h_quadsum && a.d_quad && a.quad_thr && a.m <= 32 && t.credits && t.quad && std::isfinite(a.thr_seq)))
         return false;
     constexpr int QUAD_TILE = BLOCK * 16;
     const int nq = (a.m + 3) / 4, nd = (nq + 1) / 2;
@@ -1631,7 +1509,9 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
     const unsigned grid = (unsigned)((a.n_pos + LET_TILE - 1) / LET_TILE);
     // 8 windows per thread (hits: 0.39 vs 0.49 ms on C2 w=12; scores, with the LDS transpose that keeps
     // the stores 1 KiB contiguous: 0.39 vs 0.42 ms on C2 w=8; without the transpose 0.56 ms)
-    if (a.hits && a.pair_table) {
+    if (a.hits && a.f64_hits)            // generic alphabet, fp64 compare and score (matrix.py:25-43): the exact kernel
+        hipLaunchKernelGGL((k_letters<NDW, double, true, 8>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else if (a.hits && a.pair_table) {
         // >= 2048 workgroups when the stream allows, at most 32 tiles per workgroup
         ScanArgs b = a;
         const int64_t ntiles = (a.n_pos + LET_TILE - 1) / LET_TILE;
@@ -1657,6 +1537,7 @@ static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t
     hipError_t e = hipSuccess;
     if (launch_letters_quad(a, t, stream, &e)) return e;     // PFMSCAN_QUAD=1 only: measured slower ("tried")
     if (launch_letters_cred(a, t, stream, &e)) return e;
+    if (launch_letters_cred8(a, t, stream, &e)) return e;    // fp64 hits of a generic alphabet at a finite threshold
     if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
     if (a.m <= 32) return launch_letters_ndw<9>(a, t, stream);
     return launch_letters_ndw<17>(a, t, stream);
@@ -1740,7 +1621,7 @@ __global__ __launch_bounds__(BLOCK) void k_wide(const ScanArgs a)
     if (a.hits) {
         bool pass = in;
         if (has_st) pass = pass && (st > a.thr_struct);
-        if (has_seq) pass = pass && ((double)(float)sq > a.thr_seq);
+        if (has_seq) pass = pass && ((a.f64_hits ? sq : (double)(float)sq) > a.thr_seq);
         // a letters-only scan reports its fp64 score in hit_struct (k_letters does), a scan with a structure part the structure score
         emit_hits_block<1>(pass ? 1u : 0u, [&](int) { return p; }, [&](int) { return (float)sq; }, [&](int) { return has_st ? st : sq; }, a);
         return;

@@ -102,7 +102,7 @@ int pfmscan_hits_pipeline_host(pfmscan_ctx *ctx, const pfmscan_motif *mo, const 
         if (k + 1 < n_chunks && (rc = upload(k + 1))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
-    return finish_sorted_hits(ctx, mo, n_pos, capacity, shard_cap, hit_pos, hit_seq, hit_struct, n_hits);
+    return finish_sorted_hits(ctx, mo->d_letters != nullptr, mo->d_struct != nullptr, n_pos, capacity, shard_cap, hit_pos, hit_seq, hit_struct, n_hits);
 }
 
 }  // extern "C"

@@ -168,6 +168,11 @@ class FastaSlice(object):
         everything else foreign) -- by pfmscan_fasta_encode; None when a record does not sit in a plain file."""
         return self.parent._pack(self.lo, self.hi, pack._RNA_LUT)
 
+    def pack_letters(self, lut):
+        """the same for any 256-entry letter LUT (a generic alphabet: pack.letter_lut): no transcription, no upper-casing
+        (rnascan.py:186-197 leaves structure strings as they are)"""
+        return self.parent._pack(self.lo, self.hi, lut)
+
 
 def _has_lone_cr(path, probe=1 << 20):
     """True when the file's first MiB holds a carriage return that is not part of \\r\\n: universal newlines make it a
@@ -354,19 +359,28 @@ def preprocess_seq(seq, target_is_rna, source_is_rna=False):
     return seq
 
 
-def _count_rna_natively(fasta_files, positions=1 << 26):
-    """A, C, G, U counts of plain FASTA files through the native packer (batches of ``positions`` letters), or None
-    when a file is compressed"""
+def _count_letters_natively(fasta_files, lut, positions=1 << 26):
+    """counts of the codes 0..7 of plain FASTA files through the native packer (batches of ``positions`` letters), or
+    None when a file cannot be mapped (compressed, CR-only line ends)"""
     files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
     if any(os.path.splitext(f)[1] in (".gz", ".bz2") for f in files):
         return None
     from . import shard
     lazy = LazyFasta(files)
-    counts = np.zeros(8, dtype=np.int64)
+    counts = np.zeros(256, dtype=np.int64)
     for lo, hi in shard.batches(lazy.lengths, 0, len(lazy), positions):
         if hi > lo:
-            counts += np.bincount(lazy[lo:hi].pack_rna()[0], minlength=8)
-    return counts[:4]
+            packed = lazy[lo:hi].pack_letters(lut)
+            if packed is None:
+                return None
+            counts += np.bincount(packed[0], minlength=256)
+    return counts[:8]
+
+
+def _count_rna_natively(fasta_files, positions=1 << 26):
+    """A, C, G, U counts (preprocess_seq + count, natively)"""
+    counted = _count_letters_natively(fasta_files, pack._RNA_LUT, positions)
+    return None if counted is None else counted[:4]
 
 
 def compute_background(fasta_files, letters, verbose=True):
@@ -376,10 +390,15 @@ def compute_background(fasta_files, letters, verbose=True):
     content = {}
     total = len(letters)
     is_rna = is_rna_letters(letters)
-    counted = _count_rna_natively(fasta_files) if is_rna else None
+    if is_rna:
+        counted, where = _count_rna_natively(fasta_files), pack.RNA_LETTERS
+    else:
+        # a generic alphabet is counted as written (no upper-casing, rnascan.py:186-197; Seq.count is case-sensitive):
+        # with the case-keeping LUT the codes 0..6 are exactly the upper-case letters
+        counted, where = _count_letters_natively(fasta_files, pack.letter_lut(letters, keep_case=True)), letters
     if counted is not None:                    # the same counts from the packed codes (preprocess_seq + count, natively)
         for letter in letters:
-            content[letter] = int(counted[pack.RNA_LETTERS.index(letter)])
+            content[letter] = int(counted[where.index(letter)])
             total += content[letter]
     else:
         for rec in parse_sequences(fasta_files):

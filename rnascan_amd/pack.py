@@ -25,20 +25,27 @@ def encode_rna(seq):
     return _RNA_LUT[b]
 
 
-def letter_lut(letters):
-    """LUT for a generic alphabet; ``_py_calculate`` upper-cases first (matrix.py:31)."""
+CASE_BIT = 8                         # bit 3 of a generic-alphabet code: the input wrote the letter in lower case
+
+
+def letter_lut(letters, keep_case=False):
+    """LUT for a generic alphabet; ``_py_calculate`` upper-cases first (matrix.py:31), so both cases score alike.
+    ``keep_case``: a lower-case letter gets its index | CASE_BIT -- the kernels read bits 0..2 only (include/pfmscan.h),
+    and the ``Sequence`` column can show the structure string as it was written (rnascan.py:186-197 does not upper-case
+    it, :272 slices the record itself)."""
     if len(letters) > SEP:
         raise ValueError("at most 7 letters per alphabet")
     lut = np.full(256, SEP, dtype=np.uint8)
     for i, ch in enumerate(letters):
-        lut[ord(ch)] = i
-        lut[ord(ch.lower())] = i
+        lut[ord(ch.upper())] = i
+        if ch.lower() != ch.upper():
+            lut[ord(ch.lower())] = i | (CASE_BIT if keep_case else 0)
     return lut
 
 
-def encode_letters(seq, letters):
-    b = np.frombuffer(seq.encode("latin-1") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
-    return letter_lut(letters)[b]
+def encode_letters(seq, letters, keep_case=False):
+    b = np.frombuffer(seq.encode("latin-1", "replace") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    return letter_lut(letters, keep_case)[b]
 
 
 class Stream(object):
@@ -50,8 +57,9 @@ class Stream(object):
     lengths  int64 [R]   record lengths (without the separator)
     """
 
-    def __init__(self, codes, profile, offsets, lengths):
+    def __init__(self, codes, profile, offsets, lengths, codes2=None):
         self.codes = codes
+        self.codes2 = codes2            # second code stream of the same records (two-FASTA combined scan), or None
         self.profile = profile
         self.offsets = offsets
         self.lengths = lengths

@@ -30,31 +30,51 @@ class HipEngine(object):
     The last stream stays staged on the device: scanning the same ``Stream`` object
     with another motif (a multi-PFM library) re-uses it without any upload."""
 
+    MOTIF_CACHE = 8                 # motifs kept on the device between calls (a CLI run scans every batch with the same few)
+
     def __init__(self, device=0):
         self.ctx = _lib.Context(device)
         self._staged = None
+        self._staged2 = None        # the Stream whose codes2 are staged beside the staged codes
         self._library = None        # (key, _lib.Library): the tables of the last library stay on the device across batches
+        self._motifs = {}           # (letter table bytes, structure PSSM bytes) -> _lib.Motif, in order of last use
 
     def close(self):
         if self._library is not None:
             self._library[1].close()
             self._library = None
+        for mo in self._motifs.values():
+            mo.close()
+        self._motifs = {}
         self.ctx.close()
+
+    def _motif(self, letter_table=None, struct_pssm=None):
+        """the device-resident operands of a motif, kept across calls: with them stay the threshold-dependent tables the
+        hits kernels derive on the host (credit tables and their survivor prediction), which a batch-by-batch CLI run
+        would otherwise rebuild for every batch"""
+        lt = None if letter_table is None else np.ascontiguousarray(letter_table, dtype=np.float64)
+        sp = None if struct_pssm is None else np.ascontiguousarray(struct_pssm, dtype=np.float64)
+        key = (None if lt is None else (lt.shape, lt.tobytes()), None if sp is None else (sp.shape, sp.tobytes()))
+        mo = self._motifs.pop(key, None)
+        if mo is None:
+            mo = self.ctx.motif(lt, sp)
+            while len(self._motifs) >= self.MOTIF_CACHE:
+                self._motifs.pop(next(iter(self._motifs))).close()
+        self._motifs[key] = mo                              # most recently used last
+        return mo
 
     def _stage(self, stream):
         if self._staged is None or self._staged[0] is not stream or self._staged[1] != self.ctx.scratch_gen:
             self._staged = None
+            self._staged2 = None
             gen = self.ctx.stage(stream.codes, stream.profile)
             self._staged = (stream, gen)
 
     def scan(self, stream, letter_table=None, struct_pssm=None):
         """all window scores, position aligned -> (float32 seq | None, float64 struct | None)"""
-        motif = self.ctx.motif(letter_table, struct_pssm)
-        try:
-            self._stage(stream)
-            return self.ctx.scan_staged(motif)
-        finally:
-            motif.close()
+        motif = self._motif(letter_table, struct_pssm)
+        self._stage(stream)
+        return self.ctx.scan_staged(motif)
 
     def pwm_calculate(self, sequence, matrix):
         """``_pwm.calculate(sequence, matrix)`` (_pwm.c:79-121): str + float64 [m][4] (A,C,G,U) -> float32 [n]"""
@@ -63,12 +83,25 @@ class HipEngine(object):
 
     def scan_letters_f64(self, stream, letter_table):
         """generic-alphabet letter scores in fp64 (matrix.py:25-43)"""
-        motif = self.ctx.motif(letter_table, None)
-        try:
-            self._staged = None
-            return self.ctx.scan_letters_f64_host(motif, stream.codes)
-        finally:
-            motif.close()
+        self._staged = None
+        return self.ctx.scan_letters_f64_host(self._motif(letter_table, None), stream.codes)
+
+    def hits_letters_f64(self, stream, letter_table, thr):
+        """positions (sorted) whose fp64 letter score exceeds thr (matrix.py:25-43 + rnascan.py:263) -> (pos, score float64)"""
+        motif = self._motif(letter_table, None)
+        self._stage(stream)
+        return self.ctx.hits_letters_f64_staged(motif, thr)
+
+    def hits_pair(self, stream, seq_table, struct_table, thr_seq, thr_struct):
+        """positions (sorted) where the letters of ``stream.codes`` score above thr_seq (float32 of the fp64 sum) AND the
+        letters of ``stream.codes2`` above thr_struct (fp64) -- the two-FASTA combined scan (rnascan.py:416-434 joins the
+        two hit tables) -> (pos, seq float32, struct float64)"""
+        mo_seq, mo_st = self._motif(seq_table, None), self._motif(struct_table, None)
+        self._stage(stream)
+        if self._staged2 is not stream:
+            self.ctx.stage_codes2(stream.codes2)
+            self._staged2 = stream
+        return self.ctx.hits_pair_staged(mo_seq, mo_st, thr_seq, thr_struct)
 
     def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf, one_shot=True):
         """positions (sorted) whose scores exceed the thresholds -> (pos, seq | None, struct | None).
@@ -76,18 +109,15 @@ class HipEngine(object):
         a large batch) goes through the chunked pipeline: upload and scan overlap, device scratch stays two chunks --
         when this is the ONLY scan of the stream (``one_shot``).  A caller that loops over motifs says so: the stream is
         then staged once for all of them (the pipeline leaves nothing staged, every motif would upload it again)."""
-        motif = self.ctx.motif(letter_table, struct_pssm)
-        try:
-            staged = self._staged is not None and self._staged[0] is stream and self._staged[1] == self.ctx.scratch_gen
-            if one_shot and not staged and stream.n_pos > PIPELINE_MIN:
-                self._staged = None
-                return self.ctx.hits_pipeline_host(motif, stream.codes if letter_table is not None else None,
-                                                   stream.profile if struct_pssm is not None else None, thr_seq, thr_struct,
-                                                   PIPELINE_CHUNK)
-            self._stage(stream)
-            return self.ctx.hits_staged(motif, thr_seq, thr_struct)
-        finally:
-            motif.close()
+        motif = self._motif(letter_table, struct_pssm)
+        staged = self._staged is not None and self._staged[0] is stream and self._staged[1] == self.ctx.scratch_gen
+        if one_shot and not staged and stream.n_pos > PIPELINE_MIN:
+            self._staged = None
+            return self.ctx.hits_pipeline_host(motif, stream.codes if letter_table is not None else None,
+                                               stream.profile if struct_pssm is not None else None, thr_seq, thr_struct,
+                                               PIPELINE_CHUNK)
+        self._stage(stream)
+        return self.ctx.hits_staged(motif, thr_seq, thr_struct)
 
 
 def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct=None, one_shot=True):
@@ -143,19 +173,39 @@ def _select(engine, stream, m, letter_table, struct_pssm, thr_seq, thr_struct, o
     return pos, sq, st
 
 
+def _select_letters_f64(engine, stream, m, letter_table, thr):
+    """hits of a generic-alphabet letter scan (Python floats in the reference: fp64, no float32 cast; matrix.py:25-43)
+    -> (pos, score).  Finite thresholds are decided on the device; at -inf every window with a finite score is a row,
+    so the all-scores kernel runs and the same strict `>` drops NaN and -inf here."""
+    if np.isneginf(thr) or not hasattr(engine, "hits_letters_f64"):
+        full = engine.scan_letters_f64(stream, letter_table)
+        pos = np.flatnonzero(stream.window_mask(m) & (full > thr))
+        return pos, full[pos]
+    return engine.hits_letters_f64(stream, letter_table, thr)
+
+
 # ---------------------------------------------------------------------------
 # sequence / letter-string scans
 # ---------------------------------------------------------------------------
 class _RnaBatch(object):
-    """A batch of nucleotide records in stream form: the codes (one separator after each record), and where the
+    """A batch of records in stream form: the codes (one separator after each record), and where the
     strings of a record are found when a hit needs them.  From a fasta.FastaSlice the letters are mapped and packed
     natively from the mapped file (pfmscan_fasta_encode); from Records by preprocess_seq (rnascan.py:186-197) +
     pack.encode_rna.  Either way a hit's ``Sequence`` is read back from the codes: a hit window holds the four
     nucleotides only (a foreign letter makes the window NaN), and preprocess_seq upper-cases and turns T into U,
-    which is what codes 0..3 -> ``ACGU`` gives."""
+    which is what codes 0..3 -> ``ACGU`` gives.
 
-    def __init__(self, records):
-        packed = records.pack_rna() if hasattr(records, "pack_rna") else None
+    ``letters``: a generic alphabet (structure strings, ``EHTBLRM``) instead of the nucleotides.  Its records are NOT
+    transcribed or upper-cased (rnascan.py:186-197), the scores ignore the case (matrix.py:31) and the ``Sequence``
+    column shows the string as written (rnascan.py:272): the codes keep the case in bit 3 (pack.CASE_BIT), which the
+    kernels do not read."""
+
+    def __init__(self, records, letters=None):
+        self.letters = letters
+        if letters is None:
+            packed = records.pack_rna() if hasattr(records, "pack_rna") else None
+        else:
+            packed = records.pack_letters(pack.letter_lut(letters, keep_case=True)) if hasattr(records, "pack_letters") else None
         self.spans = None                      # (file bytes, id spans, header spans): strings the writer copies itself
         if packed is not None:
             self.codes, self.offsets, self.lengths = packed
@@ -163,7 +213,10 @@ class _RnaBatch(object):
             self.spans = records.span_tables()
         else:
             recs = list(records)
-            coded = [pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs]
+            if letters is None:
+                coded = [pack.encode_rna(fasta.preprocess_seq(r.seq, True)) for r in recs]
+            else:
+                coded = [pack.encode_letters(r.seq, letters, keep_case=True) for r in recs]
             st = pack.pack(coded) if recs else None
             self.codes = st.codes if st else np.zeros(0, dtype=np.uint8)
             self.offsets = st.offsets if st else np.zeros(0, dtype=np.int64)
@@ -178,7 +231,7 @@ class _RnaBatch(object):
         """the batch restricted to records ``keep`` (ascending indices)"""
         if len(keep) == len(self):
             return self
-        out = _RnaBatch([])
+        out = _RnaBatch([], self.letters)
         parts = [self.codes[int(self.offsets[i]):int(self.offsets[i] + self.lengths[i]) + 1] for i in keep]
         out.codes = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
         out.lengths = self.lengths[keep]
@@ -190,6 +243,12 @@ class _RnaBatch(object):
         if self.spans is not None:
             out.spans = (self.spans[0], self.spans[1][keep], self.spans[2][keep])
         return out
+
+    def windows(self, pos, m):
+        """the ``Sequence`` column of hits at stream positions ``pos``"""
+        if self.letters is None:
+            return table.Windows(self.codes, pos, m, pack.RNA_LETTERS)
+        return table.Windows(self.codes, pos, m, self.letters, cased=True)
 
     def id_column(self, rec):
         return table.Spans(self.spans[0], self.spans[1], rec) if self.spans is not None else table.Indexed(self.ids, rec)
@@ -224,29 +283,14 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
         records = list(records)                                 # any iterable of Records
     if not len(records):
         return pd.DataFrame(columns=SEQ_COLUMNS)
-    if is_rna:
-        order = pack.RNA_LETTERS                               # sorted(alphabet.letters), matrix.py:57
-        batch = _RnaBatch(records)
-        stream = pack.Stream(batch.codes, None, batch.offsets, batch.lengths)   # packed (and staged on the device) once
-        id_column, description_column = batch.id_column, batch.description_column
+    # sorted(alphabet.letters) for nucleotides (matrix.py:57); a generic alphabet in its own order
+    order = pack.RNA_LETTERS if is_rna else letters
+    batch = _RnaBatch(records, None if is_rna else letters)    # packed natively from the mapped file when it can be
+    stream = pack.Stream(batch.codes, None, batch.offsets, batch.lengths)       # (and staged on the device once)
+    id_column, description_column = batch.id_column, batch.description_column
 
-        def fragments(pos, rec, start, m):
-            return table.Windows(stream.codes, pos, m, order)
-    else:
-        order = letters
-        recs = list(records)
-        seqs = [r.seq for r in recs]                            # structure strings are not upper-cased (rnascan.py:186-197)
-        stream = pack.pack([pack.encode_letters(s, order) for s in seqs])       # _py_calculate upper-cases, matrix.py:31
-        ids, descriptions = [r.id for r in recs], [r.description for r in recs]
-
-        def id_column(rec):
-            return table.Indexed(ids, rec)
-
-        def description_column(rec):
-            return table.Indexed(descriptions, rec)
-
-        def fragments(pos, rec, start, m):
-            return [seqs[r][s:s + m] for r, s in zip(rec.tolist(), start.tolist())]
+    def fragments(pos, rec, start, m):
+        return batch.windows(pos, m)
     tables = []
 
     def rows(motif_ids, m, pos, mo, logodds):
@@ -273,10 +317,8 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
                 pos, sq, _ = _select(engine, stream, m, tab, None, float(minscore), -np.inf, one_shot=len(pssm) == 1)
                 logodds = np.round(sq, 3)                      # round(np.float32, 3) stays float32 (rnascan.py:273)
             else:
-                full = engine.scan_letters_f64(stream, tab)     # Python floats in the reference: fp64, no f32 cast
-                keep = stream.window_mask(m) & (full > float(minscore))
-                pos = np.flatnonzero(keep)
-                logodds = np.array([round(float(x), 3) for x in full[pos]], dtype=np.float64)
+                pos, sc = _select_letters_f64(engine, stream, m, tab, float(minscore))
+                logodds = _lib.round_decimals(sc, 3)            # round(Python float, 3), rnascan.py:273
             tables.append(rows([motif_id], m, pos, None, logodds))
     return _finish(tables, SEQ_COLUMNS, ["Start", "Motif_ID"], columns)
 
@@ -480,6 +522,47 @@ def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minsco
         profs.append(prof)
     stream = pack.Stream(batch.codes, pack.pack(profiles=profs, profile_dtype=profile_dtype).profile, batch.offsets, batch.lengths)
     return _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, struct_pssm, minscore, pairing, columns)
+
+
+def scan_pair(engine, seq_records, struct_records, seq_pssm, struct_pssm, minscore, columns=False):
+    """Sequence FASTA + structure FASTA in ONE call per motif pair (`rnascan -p .. -q .. seqs.fa structs.fa`,
+    rnascan.py:119-123): equivalent to ``combine(scan_main(seqs), scan_main(structs))`` (rnascan.py:416-434) when the
+    two batches hold the same records -- same ids in the same order, each id once, same lengths.  The letters of both
+    files go to the device as two code streams with the same layout; a window is reported for the motif pair (a, b) iff
+    seq_a > minscore AND struct_b > minscore.  Returns None when the batches cannot be paired that way (the caller then
+    makes the two tables and joins them)."""
+    pairs_m = pair_motifs(seq_pssm, struct_pssm)
+    if pairs_m is None:
+        return None
+    sb, tb = _RnaBatch(seq_records), _RnaBatch(struct_records, fasta.STRUCT)
+    ids = list(sb.ids)
+    if len(sb) != len(tb) or ids != list(tb.ids) or len(set(ids)) != len(ids) or not np.array_equal(sb.lengths, tb.lengths):
+        return None
+    if not len(sb) or not pairs_m:
+        return pd.DataFrame(columns=COMBINED_COLUMNS)
+    stream = pack.Stream(sb.codes, None, sb.offsets, sb.lengths, codes2=tb.codes)
+    thr = float(minscore)
+    tables = []
+    for a, b in pairs_m:
+        m = seq_pssm[a].length
+        tab_seq = seq_pssm[a].letter_table(pack.RNA_LETTERS)
+        tab_st = struct_pssm[b].letter_table(fasta.STRUCT)
+        if np.isneginf(thr) or not hasattr(engine, "hits_pair"):
+            # every window with two finite scores is a row: all scores of both sides, the same strict `>` on the host
+            sq, _ = engine.scan(stream, tab_seq, None)
+            st = engine.scan_letters_f64(pack.Stream(tb.codes, None, tb.offsets, tb.lengths), tab_st)
+            pos = np.flatnonzero(stream.window_mask(m) & (sq.astype(np.float64) > thr) & (st > thr))
+            sq, st = sq[pos], st[pos]
+        else:
+            pos, sq, st = engine.hits_pair(stream, tab_seq, tab_st, thr, thr)
+        rec, start = stream.locate(pos)
+        lo_seq, lo_st = np.round(sq, 3), _lib.round_decimals(st, 3)       # rnascan.py:273 on a float32 / on a Python float
+        tables.append({
+            "_rec": rec, "Sequence_ID": sb.id_column(rec), "Description.Seq": sb.description_column(rec), "Motif_ID.Seq": a,
+            "Start": start + 1, "End": start + m, "Sequence.Seq": sb.windows(pos, m), "LogOdds.Seq": lo_seq,
+            "Description.Struct": tb.description_column(rec), "Motif_ID.Struct": b, "Sequence.Struct": tb.windows(pos, m),
+            "LogOdds.Struct": lo_st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + lo_st})
+    return _finish(tables, COMBINED_COLUMNS, ["Start", "Motif_ID.Seq", "Motif_ID.Struct"], columns)
 
 
 def _scan_combined_stream(engine, stream, batch, letters0, pairs_m, seq_pssm, struct_pssm, minscore, pairing, columns):

@@ -58,20 +58,26 @@ class Windows(object):
     """The ``Sequence`` column given as stream positions into a code array: row r holds the ``m`` letters
     ``letters[codes[pos[r] + j]]`` (rnascan.py:272 slices the record string per hit)."""
 
-    def __init__(self, codes, pos, m, letters):
+    def __init__(self, codes, pos, m, letters, cased=False):
         self.codes = codes
         self.pos = np.asarray(pos, dtype=np.int64)
         self.m = int(m)
         self.letters = letters
+        self.cased = cased                      # codes 8..15 = the same letters written in lower case (pack.CASE_BIT)
 
     def __len__(self):
         return self.pos.shape[0]
 
+    def blob(self):
+        """the 16 letters of codes 0..15 (PFMSCAN_TSV_WINDOW)"""
+        upper = self.letters.ljust(8, "?")
+        return (upper + (self.letters.lower().ljust(8, "?") if self.cased else "?" * 8)).encode("ascii")
+
     def materialize(self):
-        lut = np.frombuffer(self.letters.ljust(8, "?").encode("ascii"), dtype=np.uint8)
+        lut = np.frombuffer(self.blob(), dtype=np.uint8)
         if self.pos.size == 0 or self.m == 0:
             return np.full(self.pos.size, "", dtype=object)
-        win = lut[self.codes[self.pos[:, None] + np.arange(self.m)] & 7]
+        win = lut[self.codes[self.pos[:, None] + np.arange(self.m)] & 15]
         return np.ascontiguousarray(win).view("S%d" % self.m).reshape(-1).astype(str).astype(object)
 
 
@@ -90,7 +96,7 @@ def _rows(col, a, b):
     if isinstance(col, Spans):
         return Spans(col.buffer, col.spans, col.index[a:b])
     if isinstance(col, Windows):
-        return Windows(col.codes, col.pos[a:b], col.m, col.letters)
+        return Windows(col.codes, col.pos[a:b], col.m, col.letters, col.cased)
     if column_length(col) is None:
         return col
     return col[a:b]
@@ -152,7 +158,7 @@ def _descriptor(col, n):
     if isinstance(col, Windows):
         if len(col) != n:
             raise ValueError("column length mismatch")
-        return (_lib.TSV_WINDOW, col.pos, col.codes, col.letters.ljust(8, "?").encode("ascii"), col.m)
+        return (_lib.TSV_WINDOW, col.pos, col.codes, col.blob(), col.m)
     if isinstance(col, (list, tuple)):
         if len(col) != n:
             raise ValueError("column length mismatch")

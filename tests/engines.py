@@ -18,6 +18,19 @@ class OracleEngine(object):
     def scan_letters_f64(self, stream, letter_table):
         return oracle.stream_letters_f64(stream.codes, letter_table)
 
+    def hits_letters_f64(self, stream, letter_table, thr):
+        """fp64 letter scores above thr (matrix.py:25-43 + the strict `>` of rnascan.py:263) -> (pos, score)"""
+        sc = oracle.stream_letters_f64(stream.codes, letter_table)
+        pos = oracle.stream_hits(None, sc, -np.inf, thr)
+        return pos, sc[pos]
+
+    def hits_pair(self, stream, seq_table, struct_table, thr_seq, thr_struct):
+        """two code streams: float32 sequence score AND fp64 structure-letter score above their thresholds"""
+        sq = oracle.stream_seq(stream.codes, seq_table)
+        st = oracle.stream_letters_f64(stream.codes2, struct_table)
+        pos = oracle.stream_hits(sq, st, thr_seq, thr_struct)
+        return pos, sq[pos], st[pos]
+
     def hits(self, stream, letter_table=None, struct_pssm=None, thr_seq=-np.inf, thr_struct=-np.inf, one_shot=True):
         sq, st = self.scan(stream, letter_table, struct_pssm)
         pos = oracle.stream_hits(sq, st, thr_seq, thr_struct)
