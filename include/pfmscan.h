@@ -345,6 +345,13 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
  * 4t .. 4t+3, 16-bit credits.  A window whose credits sum modulo 2^16 has bit 15 clear cannot be a hit. */
 int pfmscan_debug_quad_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack);
 
+/* The same for the SINGLE-letter credit table of the generic-alphabet hits kernel (k_letters_cred8, PFMs up to width 32,
+ * letter_table double [m][8] with up to 7 letters): credits uint16 [m][8], entry index = the letter code; NaN and -inf
+ * cells and the foreign code get no credit.  *mode = 1: the kernel uses the table; 2: more than 1/32 of the windows would
+ * survive it, the exact kernel runs instead; 3: no prefilter possible (+inf cells).  A window whose credits sum modulo 2^16
+ * has bit 15 clear cannot be a hit (fp64 score > thr, matrix.py:25-43). */
+int pfmscan_debug_credit8_table(const double *letter_table, int m, double thr, uint16_t *credits, int *mode);
+
 /* How the `_host` / `pfmscan_stage` / pipeline entry points move host memory to the device.
  *   PFMSCAN_UPLOAD_RUNTIME (default): hipMemcpyAsync from the caller's pages; the runtime pins them in place, which
  *     reaches the PCIe rate for ordinary (anonymous) memory.

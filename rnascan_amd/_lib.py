@@ -33,7 +33,7 @@ SYMBOLS = [
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
-    "pfmscan_debug_quad_table",
+    "pfmscan_debug_quad_table", "pfmscan_debug_credit8_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
     "pfmscan_hits_pair_dev", "pfmscan_stage_codes2", "pfmscan_hits_pair_staged", "pfmscan_hits_pair_host", "pfmscan_round_decimals",
@@ -127,6 +127,7 @@ def load():
     L.pfmscan_library_hits_pipeline_host.argtypes = [vp, vp, vp, vp, i32, i64, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_debug_credit_table.argtypes = [vp, i32, dbl, i32, vp, ctypes.POINTER(dbl)]
     L.pfmscan_debug_quad_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(dbl)]
+    L.pfmscan_debug_credit8_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(i32)]
     L.pfmscan_set_upload_mode.argtypes = [vp, i32]
     L.pfmscan_upload_source_file.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
@@ -881,6 +882,21 @@ def quad_table(letter_table, thr_seq):
     if rc != OK:
         raise ValueError("pfmscan_debug_quad_table: bad argument")
     return out, slack.value
+
+
+def credit8_table(letter_table, thr):
+    """Host-only diagnostic: the single-letter credit table of k_letters_cred8 for ONE generic-alphabet motif (width <= 32)
+    -> (credits uint16 [m][8], mode).  mode 1: used; 2: dense threshold (exact kernel instead); 3: no prefilter possible."""
+    L = load()
+    T = np.ascontiguousarray(letter_table, dtype=np.float64)
+    if T.ndim != 2 or T.shape[1] != NCODE:
+        raise ValueError("letter_table must be [m][8]")
+    out = np.zeros((T.shape[0], 8), dtype=np.uint16)
+    mode = ctypes.c_int(0)
+    rc = L.pfmscan_debug_credit8_table(_ptr(T), T.shape[0], float(thr), _ptr(out), ctypes.byref(mode))
+    if rc != OK:
+        raise ValueError("pfmscan_debug_credit8_table: bad argument")
+    return out, mode.value
 
 
 def _stream_args(motif, codes, profile):

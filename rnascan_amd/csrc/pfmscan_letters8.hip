@@ -28,6 +28,7 @@
 //              two-FASTA combined scan (RNA letters pass over everything, the structure letters only at its hits).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -42,7 +43,7 @@ struct Cred8Table {
 constexpr int Q8_CAP = 128;                            // hits a wave can park (12 bytes each)
 
 template <int NJ>
-__global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const Cred8Table ct)
+__global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
 {
     constexpr int W = 16;                              // windows per lane = one round per tile
     constexpr int LET_TILE = BLOCK * W;
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const
     cs.fetch(a.codes, first, n_pos);
     // rows m .. are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
     for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
-    for (int i = threadIdx.x; i < 8 * EDW; i += BLOCK) ctab[i] = (i & (EDW - 1)) < NJ ? ct.d[i >> (ESH - 2)][i & (EDW - 1)] : 0u;
+    // the credit table comes from device memory (a.d_cred8, [8][16] dwords): as a by-value kernel argument its per-lane
+    // indexing kept all 128 dwords in SGPRs and the widest instantiation spilled 57 of them to VGPR lanes
+    for (int i = threadIdx.x; i < 8 * EDW; i += BLOCK) ctab[i] = (i & (EDW - 1)) < NJ ? a.d_cred8[(i >> (ESH - 2)) * 16 + (i & (EDW - 1))] : 0u;
     if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
     cs.park(cbuf[0]);
     if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
@@ -170,6 +173,10 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
             const uint32_t off = ((xs[q >> 2] >> (8 * (q & 3))) & 0xFFu) << (ESH - PSH);
+            // position q feeds the windows u = q - 2k in [0, W], i.e. the row pairs k in [(q - W + 1) / 2, q / 2]: at most
+            // W / 2 + 1 of the NJ dwords of its entry -- only the 16-byte groups that hold one of them are read
+            constexpr int KMAX = NJ - 1;
+            const int klo = q > W ? (q - W + 1) / 2 : 0, khi = q / 2 < KMAX ? q / 2 : KMAX;
             uint32_t dj[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             if constexpr (NJ <= 2) {
                 const u32x2 e = *reinterpret_cast<const u32x2 *>(cbytes + off);
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const
             } else {
 #pragma unroll
                 for (int g = 0; g < (NJ + 3) / 4; ++g) {
+                    if (4 * g > khi || 4 * g + 3 < klo) continue;      // compile-time after unrolling
                     if (NJ - 4 * g >= 3) {
                         const u32x4 e = *reinterpret_cast<const u32x4 *>(cbytes + off + 16 * g);
 #pragma unroll
@@ -195,27 +203,28 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const
                 if (u >= 0 && u <= W) pk[u] += dj[k];
             }
         }
-        uint32_t sum[W];
-        uint32_t any = 0;
+        // bit v of `surv` = window v of this lane may be a hit
+        uint32_t surv = 0;
 #pragma unroll
         for (int v = 0; v < W; ++v) {
-            sum[v] = (pk[v] & 0xFFFFu) + (pk[v + 1] >> 16);
-            any |= sum[v];
+            const uint32_t sum = (pk[v] & 0xFFFFu) + (pk[v + 1] >> 16);
+            surv |= ((sum >> 15) & 1u) << v;
         }
-        // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes: no credit)
-        if (__builtin_amdgcn_ballot_w64((any & 0x8000u) != 0)) {
-#pragma unroll
-            for (int v = 0; v < W; ++v) {
-                const bool sv = (sum[v] & 0x8000u) != 0;
-                const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
-                if (sb) {                               // wave-uniform
-                    if (sv) my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
-                    sv_n += __popcll(sb);
-                    if (sv_n >= 64) {                   // the top 64 get their exact score, the rest stays
-                        exact_batch(sv_n - 64, 64);
-                        sv_n -= 64;
-                    }
-                }
+        // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes: no credit).  ONE rolled
+        // loop: every pass each lane that still has a survivor hands over its lowest one (an unrolled pass per window
+        // inlined the exact score 17 times: 25 k instructions and 57 spilled SGPRs in the widest instantiation).
+        while (__builtin_amdgcn_ballot_w64(surv != 0)) {
+            const bool sv = surv != 0;
+            const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
+            if (sv) {
+                const int v = __builtin_ctz(surv);
+                surv &= surv - 1;
+                my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
+            }
+            sv_n += __popcll(sb);
+            if (sv_n >= 64) {                           // the top 64 get their exact score, the rest stays
+                exact_batch(sv_n - 64, 64);
+                sv_n -= 64;
             }
         }
 
@@ -278,7 +287,7 @@ static double credit_survival(const uint16_t *cr, int nrows, int nent, int ncol)
 
 // The single-letter credit table of a motif at threshold thr -> cc (cached with the motif).  mode 1: use the prefilter;
 // 2: dense threshold (more than 1/32 of the windows would survive); 3: no prefilter possible (+inf cells).
-static void build_cred8(const double *h_letters, int m, double thr, Cred8Cache *cc)
+void build_cred8(const double *h_letters, int m, double thr, Cred8Cache *cc)
 {
     cc->thr = thr;
     std::vector<double> rows((size_t)m * 8);
@@ -307,27 +316,40 @@ static int walk_tiles8(int64_t ntiles, const Tuning &t)
 
 bool launch_letters_cred8(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
-    if (!(a.hits && a.f64_hits && a.h_letters && a.cred8_cache && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
+    if (!(a.hits && a.f64_hits && a.h_letters && a.cred8_cache && a.d_cred8 && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
     Cred8Cache *cc = a.cred8_cache;
-    if (!(cc->thr == a.thr_seq) || cc->mode == 0) build_cred8(a.h_letters, a.m, a.thr_seq, cc);
+    if (!(cc->thr == a.thr_seq) || cc->mode == 0) {
+        build_cred8(a.h_letters, a.m, a.thr_seq, cc);
+        cc->on_device = false;
+    }
     if (cc->mode != 1) return false;                   // -> the exact kernel (k_letters<..., double, HITS>)
-    const int nj = (a.m + 1) / 2;
-    Cred8Table ct;
-    std::memset(&ct, 0, sizeof(ct));
-    for (int c = 0; c < 8; ++c)
-        for (int j = 0; j < a.m; ++j) ct.d[c][j >> 1] |= (uint32_t)cc->cr[j * 8 + c] << (16 * (j & 1));
+    int nj = (a.m + 1) / 2;
+    if (const char *v = std::getenv("PFMSCAN_CRED8_NJ")) nj = std::max(nj, std::atoi(v));   // tests: a wider bucket than the PFM needs
+    if (!cc->on_device) {
+        // the table of the call's threshold lives on the device with the motif and is rewritten only when the threshold
+        // changes; another launch (on any stream) may still read the old one: threshold changes are rare, wait for the device
+        Cred8Table ct;
+        std::memset(&ct, 0, sizeof(ct));
+        for (int c = 0; c < 8; ++c)
+            for (int j = 0; j < a.m; ++j) ct.d[c][j >> 1] |= (uint32_t)cc->cr[j * 8 + c] << (16 * (j & 1));
+        *err = hipDeviceSynchronize();
+        if (*err != hipSuccess) return true;
+        *err = hipMemcpy(a.d_cred8, &ct, sizeof(ct), hipMemcpyHostToDevice);
+        if (*err != hipSuccess) return true;
+        cc->on_device = true;
+    }
     constexpr int TILE = BLOCK * 16;
     ScanArgs b = a;
     const int64_t ntiles = (a.n_pos + TILE - 1) / TILE;
     b.tiles_per_block = walk_tiles8(ntiles, t);
     if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
     const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
-    if (nj <= 2) hipLaunchKernelGGL((k_letters_cred8<2>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-    else if (nj <= 4) hipLaunchKernelGGL((k_letters_cred8<4>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-    else if (nj <= 6) hipLaunchKernelGGL((k_letters_cred8<6>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-    else if (nj <= 8) hipLaunchKernelGGL((k_letters_cred8<8>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-    else if (nj <= 12) hipLaunchKernelGGL((k_letters_cred8<12>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
-    else hipLaunchKernelGGL((k_letters_cred8<16>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+    if (nj <= 2) hipLaunchKernelGGL((k_letters_cred8<2>), dim3(g), dim3(BLOCK), 0, stream, b);
+    else if (nj <= 4) hipLaunchKernelGGL((k_letters_cred8<4>), dim3(g), dim3(BLOCK), 0, stream, b);
+    else if (nj <= 6) hipLaunchKernelGGL((k_letters_cred8<6>), dim3(g), dim3(BLOCK), 0, stream, b);
+    else if (nj <= 8) hipLaunchKernelGGL((k_letters_cred8<8>), dim3(g), dim3(BLOCK), 0, stream, b);
+    else if (nj <= 12) hipLaunchKernelGGL((k_letters_cred8<12>), dim3(g), dim3(BLOCK), 0, stream, b);
+    else hipLaunchKernelGGL((k_letters_cred8<16>), dim3(g), dim3(BLOCK), 0, stream, b);
     *err = hipGetLastError();
     return true;
 }
@@ -408,3 +430,15 @@ hipError_t launch_letters_at(const ScanArgs &a, const int64_t *cand_pos, const f
 }
 
 }  // namespace pfmscan
+
+// Diagnostics (host only): the single-letter credit table k_letters_cred8 would use for one motif at threshold thr
+// (include/pfmscan.h).  tests/test_library_credits.py checks it exhaustively without a GPU.
+extern "C" int pfmscan_debug_credit8_table(const double *letter_table, int m, double thr, uint16_t *credits, int *mode)
+{
+    if (!letter_table || !credits || m < 1 || m > 32 || std::isnan(thr)) return PFMSCAN_E_BADARG;
+    pfmscan::Cred8Cache cc;
+    pfmscan::build_cred8(letter_table, m, thr, &cc);
+    std::memcpy(credits, cc.cr, sizeof(uint16_t) * (size_t)m * 8);
+    if (mode) *mode = cc.mode;
+    return PFMSCAN_OK;
+}

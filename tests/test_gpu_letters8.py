@@ -67,6 +67,27 @@ def test_hits_letters_f64_every_width(ctx, oracle, m):
     mo.close()
 
 
+@pytest.mark.parametrize("nj", [4, 8, 12, 16])
+def test_hits_letters_f64_every_bucket_of_the_prefilter(ctx, oracle, nj, monkeypatch):
+    """every instantiation of k_letters_cred8 on PFMs narrower than it is sized for (rows beyond the width carry no
+    credit).  The widest one once came out of the compiler wrong when it was free to use more than 128 VGPRs; it is built
+    with a register cap since (profiles/r4/NOTES.md) and this is the test that showed it."""
+    monkeypatch.setenv("PFMSCAN_CRED8_NJ", str(nj))
+    for m in (3, 2 * nj - 1, 2 * nj):
+        rng = np.random.default_rng(1000 + 10 * nj + m)
+        s = _stream(rng, [9000, m, 5000, 31])
+        T = _table(rng, m)
+        full = oracle.stream_letters_f64(s.codes, T)
+        mo = ctx.motif(T, None)
+        for q in (0.999, 0.98):
+            thr = _between(full, q)
+            pos, sc = ctx.hits_letters_f64_host(mo, s.codes, thr)
+            wpos, wsc = _want(oracle, s, T, thr)
+            assert np.array_equal(pos, wpos), (nj, m, q, pos.size, wpos.size)
+            assert np.array_equal(sc, wsc)
+        mo.close()
+
+
 def test_hits_letters_f64_special_cells_and_dense_thresholds(ctx, oracle):
     """-inf / NaN cells get no credit, +inf cells switch the prefilter off, dense thresholds take the exact kernel"""
     rng = np.random.default_rng(7)

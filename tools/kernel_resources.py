@@ -38,18 +38,18 @@ def kernels(co):
         except OSError:
             pass
         out.append((name, grab("vgpr_count"), grab("sgpr_count"), grab("group_segment_fixed_size"),
-                    grab("private_segment_fixed_size"), grab("vgpr_spill_count")))
+                    grab("private_segment_fixed_size"), grab("vgpr_spill_count"), grab("sgpr_spill_count")))
     return out
 
 
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "rnascan_amd", "libpfmscan.so")
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    print("%-110s %5s %5s %7s %7s %6s" % ("kernel", "vgpr", "sgpr", "lds", "scratch", "spill"))
+    print("%-110s %5s %5s %7s %7s %6s %6s" % ("kernel", "vgpr", "sgpr", "lds", "scratch", "vspill", "sspill"))
     for co in code_objects(path):
         for k in kernels(co):
             if flt in k[0]:
-                print("%-110s %5s %5s %7s %7s %6s" % ((re.sub(r"^void pfmscan::", "", k[0])[:110],) + k[1:]))
+                print("%-110s %5s %5s %7s %7s %6s %6s" % ((re.sub(r"^void pfmscan::", "", k[0])[:110],) + k[1:]))
 
 
 if __name__ == "__main__":
