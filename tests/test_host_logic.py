@@ -257,3 +257,35 @@ def test_cli_says_why_a_pfm_wider_than_the_kernels_is_refused(tmp_path, capsys):
     assert e.value.code == 1
     err = capsys.readouterr().err
     assert "%d positions wide" % (_lib.MAX_WIDTH + 1) in err and "at most %d" % _lib.MAX_WIDTH in err
+
+
+def test_round_decimals_is_pythons_round():
+    """rnascan.py:273 rounds every reported score with Python's round(); for the fp64 structure-letter scores that is
+    float.__round__ (nearest decimal of the exact value), which numpy.round is not"""
+    from rnascan_amd import _lib
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(0, 20, 50000), [2.6745, 1.0005, 0.0005, -0.0005, 2.675, 1e300, -1e-300, 0.0, -0.0, np.inf, np.nan,
+                                                   -np.inf, 1.2345e15, 5e-4, 1.5e-3, 2.5e-3, 4503599627370495.5, 1e22],
+                        np.round(rng.normal(0, 5, 20000), 3) + 0.0005, (rng.integers(-10 ** 7, 10 ** 7, 20000) * 2 + 1) / 2000.0])
+    for nd in (3, 0, 1, 6):
+        got = _lib.round_decimals(x, nd)
+        want = np.array([round(float(v), nd) for v in x])
+        same = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (nd, x[~same][:5])
+        assert np.array_equal(np.signbit(got), np.signbit(want))
+    assert int((np.round(x, 3) != np.array([round(float(v), 3) for v in x])).sum()) > 100     # the two functions do differ
+    assert _lib.round_decimals(np.zeros(0)).size == 0
+    with pytest.raises(ValueError):
+        _lib.round_decimals(x, 16)
+
+
+def test_letter_lut_keeps_the_case_in_bit_3():
+    from rnascan_amd import pack
+    lut = pack.letter_lut("EHTBLRM", keep_case=True)
+    assert [int(lut[ord(c)]) for c in "EHTBLRM"] == list(range(7))
+    assert [int(lut[ord(c)]) for c in "ehtblrm"] == [k | pack.CASE_BIT for k in range(7)]
+    assert lut[ord("X")] == pack.SEP and lut[ord("x")] == pack.SEP and lut[0] == pack.SEP
+    plain = pack.letter_lut("EHTBLRM")
+    assert np.array_equal(plain, np.where(lut == pack.SEP, pack.SEP, lut & 7))
+    codes = pack.encode_letters("EeLlXm", "EHTBLRM", keep_case=True)
+    assert codes.tolist() == [0, 8, 4, 12, 7, 14]

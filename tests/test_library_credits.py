@@ -156,3 +156,62 @@ def test_quad_tables_of_wide_motifs():
             assert slack <= slack2 or not np.isfinite(slack2)
     with pytest.raises(ValueError):
         _lib.quad_table(np.full((33, 8), np.nan), 1.0)
+
+
+# ---- single-letter credits of the generic-alphabet hits kernel (k_letters_cred8, pfmscan_letters8.hip) ----------------
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("special", ["none", "neg_inf", "nan", "pos_inf"])
+def test_single_letter_credits_never_drop_a_hit(m, special):
+    """every window over the 8 codes (7 letters + the foreign code) of width m, thresholds on and between scores: a window
+    whose fp64 score exceeds the threshold (matrix.py:25-43 + the strict `>` of rnascan.py:263) always has bit 15 of its
+    credit sum set; NaN / -inf cells and the foreign code never get credit; +inf cells switch the prefilter off"""
+    rng = np.random.default_rng(77 * m + len(special))
+    codes = np.array(list(itertools.product(range(8), repeat=m)), dtype=np.int64)
+    for trial in range(5):
+        T = np.full((m, 8), np.nan)
+        T[:, :7] = rng.normal(-0.5, 2.5, size=(m, 7)) * rng.choice([1.0, 1.0, 25.0])
+        r = rng.random((m, 7))
+        if special == "neg_inf":
+            T[:, :7][r < 0.2] = -np.inf
+        elif special == "nan":
+            T[:, :7][r < 0.15] = np.nan
+        elif special == "pos_inf":
+            T[:, :7][r < 0.1] = np.inf
+        s = np.zeros(codes.shape[0])
+        with np.errstate(invalid="ignore"):
+            for j in range(m):
+                s = s + T[j, codes[:, j]]                              # sequential fp64 sum
+        fin = np.sort(s[np.isfinite(s)])
+        thrs = [6.0, 0.0, -3.5, 1e4, -1e4, -1e300]
+        if fin.size:
+            thrs += [float(fin[int(q * (fin.size - 1))]) for q in (0.0, 0.5, 0.9, 0.99, 1.0)]
+            thrs += [float(np.nextafter(fin[int(0.9 * (fin.size - 1))], -np.inf))]
+        for thr in thrs:
+            credits, mode = _lib.credit8_table(T, thr)
+            if special == "pos_inf" and np.isinf(T[:, :7]).any() and (T[:, :7] == np.inf).any():
+                assert mode == 3                                        # the exact kernel decides every window
+                continue
+            assert mode in (1, 2)
+            tot = np.zeros(codes.shape[0], dtype=np.int64)
+            for j in range(m):
+                tot += credits[j, codes[:, j]].astype(np.int64)
+            assert tot.max() <= 65535
+            flagged = (tot & 0x8000) != 0
+            with np.errstate(invalid="ignore"):
+                hit = s > thr
+            assert not (hit & ~flagged).any(), (m, special, thr)
+            assert not flagged[(codes == 7).any(axis=1)].any()          # a foreign letter: NaN, never a hit, never kept
+            if mode == 1 and hit.any() and np.isfinite(thr):            # the slack is small: kept windows lie near the threshold
+                kept = s[flagged & np.isfinite(s)]
+                span = float(np.nanmax(np.abs(T[:, :7][np.isfinite(T[:, :7])]))) * m + abs(thr) + 1.0
+                assert kept.min() > thr - 0.02 * span - 1e-6
+
+
+def test_single_letter_credits_dense_thresholds_are_flagged():
+    """mode 2 <=> more than 1/32 of uniformly drawn windows would survive (the exact kernel runs instead)"""
+    rng = np.random.default_rng(5)
+    T = np.full((6, 8), np.nan)
+    T[:, :7] = rng.normal(0, 1.0, size=(6, 7))
+    assert _lib.credit8_table(T, -50.0)[1] == 2
+    assert _lib.credit8_table(T, 4.0)[1] == 1
+    assert _lib.credit8_table(T, 1e9)[1] == 1

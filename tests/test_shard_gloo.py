@@ -266,6 +266,54 @@ def test_two_ranks_stream_their_rows_and_rank0_never_holds_a_table(tmp_path, mon
         assert not [p for p in os.listdir(tmp_path) if p.startswith("rnascan_rows_")]        # the spools are gone
 
 
+def _write_fasta_pair(tmp_path, n=23, seed=5):
+    """a sequence FASTA and a structure FASTA with the same record ids in the same order (mixed-case structure strings,
+    some foreign letters, headers that need csv quoting)"""
+    rng = np.random.default_rng(seed)
+    fa, fb = tmp_path / "seqs.fa", tmp_path / "structs.fa"
+    with open(fa, "w") as f, open(fb, "w") as g:
+        for i in range(n):
+            L = int(rng.integers(0, 400))
+            s = "".join(rng.choice(list("ACGTUacgtN"), size=L))
+            t = "".join(rng.choice(list("EHTBLRMehtblrmx"), size=L))
+            f.write(">rec%d seq %d\n" % (i, i) + "\n".join(s[k:k + 60] for k in range(0, max(L, 1), 60)) + "\n")
+            g.write(">rec%d struct%s\n" % (i, ' "q"\ttab' if i % 4 == 0 else "") + "\n".join(t[k:k + 45] for k in range(0, max(L, 1), 45)) + "\n")
+    return str(fa), str(fb)
+
+
+@pytest.mark.timeout(600)
+def test_two_fasta_rnass_streams_under_two_ranks_without_table_gathers(tmp_path, monkeypatch):
+    """`rnascan -p .. -q .. seqs.fa structs.fa` (rnascan.py:119-123): one rank prints combine() of the two single tables
+    (rnascan.py:416-434, made here through the reference-shaped two-table path); two ranks stream the fused scan's rows
+    through their spools -- any gather of tables fails the run -- and give the same bytes."""
+    import io
+    import torch.multiprocessing as mp
+    from engines import OracleEngine
+    from rnascan_amd import cli
+    fa, fb = _write_fasta_pair(tmp_path)
+    pfm_s, pfm_t = tmp_path / "s.pfm", tmp_path / "t.pfm"
+    rng = np.random.default_rng(2)
+    for path, letters in ((pfm_s, "ACGU"), (pfm_t, "EHTBLRM")):
+        with open(path, "w") as f:
+            f.write("PO\t" + "\t".join(letters) + "\n")
+            for j in range(5):
+                f.write("%d\t" % j + "\t".join("%.4f" % x for x in rng.dirichlet(np.full(len(letters), 0.5))) + "\n")
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "150")
+    monkeypatch.setenv("RNASCAN_SPOOL_DIR", str(tmp_path))
+    for minscore in ("-1.5", " -inf"):
+        argv = ["-p", str(pfm_s), "-q", str(pfm_t), "-u", "-C", "0.01", "-m", minscore, fa, fb]
+        want = io.StringIO()
+        with monkeypatch.context() as mp_ctx:
+            mp_ctx.setattr(cli, "_same_records", lambda *a: None)           # two tables + combine(), as the reference does it
+            cli.main(argv, engine=OracleEngine(), out=want)
+        single = io.StringIO()
+        cli.main(argv, engine=OracleEngine(), out=single)
+        assert single.getvalue() == want.getvalue() and want.getvalue().count("\n") > 20
+        mp.spawn(_cli_worker_no_gather, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+        assert open(tmp_path / "out.0.tsv").read() == want.getvalue()
+        assert open(tmp_path / "out.1.tsv").read() == ""
+
+
 def test_tsv_number_respects_quoted_line_breaks_across_blocks():
     from rnascan_amd import _lib
     text = b'a\t1\n"x ""q""\ny"\t2\nlast\t3\n'
