@@ -67,9 +67,11 @@ def getoptions(argv=None):
                            "NOTE: the reference run on Python >= 3.6 pairs them by POSITION (file order BEHLMRT against the "
                            "PFM's EHTBLRM, rnascan.py:300-307) and therefore prints different structure scores than this "
                            "default; '--pairing positional' reproduces those numbers exactly [%(default)s]"))
-    gpu.add_argument("--profile-dtype", choices=["float64", "float32"], default="float64",
-                     help=("device storage of averaged-structure profiles: float64 reproduces the reference's "
-                           "fp64 scores to ~1e-14, float32 halves the HBM traffic and stays within 1e-6 [%(default)s]"))
+    gpu.add_argument("--profile-dtype", choices=["auto", "float64", "float32"], default="auto",
+                     help=("device storage of averaged-structure profiles: float64 reproduces the reference's fp64 scores to "
+                           "~1e-14; float32 halves the HBM traffic at a storage error of at most 2^-24 x (sum over the PFM's "
+                           "rows of the largest finite |log-odds|); auto takes float32 when that bound is below 5e-7 for the "
+                           "structure PFM at hand, else float64, and says so on stderr [%(default)s]"))
     args = parser.parse_args(argv)
     if not (args.pfm_seq or args.pfm_struct):
         parser.error("Must specify PFMs with -p and/or -q")
@@ -99,12 +101,27 @@ def _guess_seq_type(args):
     sys.exit(1)
 
 
-def store_batches(minscore):
+def profile_type(args, struct_pssm):
+    """the device storage of the profile rows for this run (scanner.pick_profile_dtype), announced once on stderr"""
+    got = getattr(args, "_profile_type", None)
+    if got is None:
+        got, bound = scanner.pick_profile_dtype(getattr(args, "profile_dtype", "auto"), struct_pssm)
+        args._profile_type = got
+        how = "as asked" if getattr(args, "profile_dtype", "auto") != "auto" else \
+            ("worst-case storage error %.1e < %.0e" % (bound, scanner.FLOAT32_STORAGE_BUDGET) if got is np.float32 else
+             "float32 storage could cost up to %.1e > %.0e" % (bound, scanner.FLOAT32_STORAGE_BUDGET))
+        fasta.eprint("Averaged-structure profiles are stored as %s on the device (%s)" % (np.dtype(got).name, how))
+    return got
+
+
+def store_batches(minscore, downcast=False):
     """batch length, in units of RNASCAN_BATCH_POSITIONS, of a scan whose profile rows are slices of a mapped store (nothing
     is copied on the host, the chunked pipeline keeps the device scratch at two chunks): 32 with a finite threshold -- the
     rows of a batch are its hits, and one long pipeline call has one ramp-up instead of one per batch -- 8 at `-m ' -inf'`,
     where every window is a row and a batch also holds its score arrays"""
     import math
+    if downcast:                 # float64 store under float32 rows: the batch is copied on the host, keep it at one unit
+        return 1
     return 32 if math.isfinite(float(minscore)) else 8
 
 
@@ -170,7 +187,6 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
     share of the records and rank 0 receives the whole table (others get None).  With one rank
     and a ``sink`` the batches' tables go to ``sink(frame)`` one by one and None is returned."""
     rank, world, dist = dist_ctx
-    ptype = np.dtype(args.profile_dtype).type
     compact = sink is not None                           # streaming: hit columns go to the native writer as they are
     if isinstance(source, fasta.Record):
         df = scanner.scan_records(engine, [source], pssm, letters, args.minscore)
@@ -204,7 +220,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         def scan_files(part):
             parsed = fasta.read_profiles([path for _, path in part])           # the files of the batch, on all cores
             named = [(sid, file_letters, prof) for (sid, _), (file_letters, prof) in zip(part, parsed)]
-            return scanner.scan_profiles(engine, named, pssm, args.minscore, args.pairing, ptype, compact)
+            return scanner.scan_profiles(engine, named, pssm, args.minscore, args.pairing, profile_type(args, pssm), compact)
 
         df = shard.scan_sharded(files, weights, scan_files, rank, world, dist, sink=sink)
         fasta.eprint("Processed %d sequences" % len(files))
@@ -338,7 +354,7 @@ def main(argv=None, engine=None, out=None):
     if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
         # sequence FASTA + averaged-structure directory (or packed store): one fused kernel pass per batch (configs 3, 5).
         # Only an index of both sides is held; a batch reads its own records and the profiles of those records.
-        ptype = np.dtype(args.profile_dtype).type
+        ptype = profile_type(args, struct_pssm)
         fasta.eprint("Scanning sequences ")
         recs = fasta.LazyFasta(seq_source)
         fasta.eprint("Processed %d sequences" % len(recs))
@@ -410,7 +426,8 @@ def main(argv=None, engine=None, out=None):
             # a packed store that holds the FASTA's records in the FASTA's order: every batch is a slice of the mapped file
             # plus its packed codes (1 byte per position) -- batches long enough for the chunked upload-beside-scan pipeline
             final = shard.scan_sharded(recs, recs.lengths, scan_pairs, rank, world, dist,
-                                       max_positions=(store_batches(args.minscore) if same_order else 1) * shard.batch_positions(),
+                                       max_positions=(store_batches(args.minscore, ps.profile.dtype == np.float64 and ptype is np.float32)
+                                                      if same_order else 1) * shard.batch_positions(),
                                        sink=stream_to(scanner.COMBINED_COLUMNS) if streaming else None)
         else:                                  # duplicate ids join across records: two whole tables + join
             named = load_many(list(where)) if ps is None else [t for sid in where for t in load(sid)]

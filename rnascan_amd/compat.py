@@ -70,7 +70,7 @@ def scan_main(fasta_file, pssm, alphabet, bg, args):
     if not hasattr(args, "pairing"):
         args.pairing = "aligned"
     if not hasattr(args, "profile_dtype"):
-        args.profile_dtype = "float64"
+        args.profile_dtype = "float64"          # the reference computes in fp64 on the values it read
     source = fasta_file if isinstance(fasta_file, str) else _record(fasta_file)
     return cli.scan_main(default_engine(), source, pssm, _letters(alphabet), args)
 

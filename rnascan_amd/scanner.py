@@ -354,6 +354,33 @@ def struct_matrix(pm, file_letters, pairing="aligned"):
     raise ValueError("pairing must be 'aligned' or 'positional'")
 
 
+FLOAT32_STORAGE_BUDGET = 0.5e-6      # half of north_star's 1e-6 on float scores is spent on storage, the rest stays for the arithmetic
+
+
+def float32_storage_bound(struct_pssm):
+    """Worst-case |score(float32 rows) - score(float64 rows)| of an averaged-structure scan (rnascan.py:302-307) with the
+    structure PSSMs ``struct_pssm`` ({id: PSSM}), over EVERY profile whose rows are non-negative and sum to at most 1:
+    rounding a row entry p to float32 moves it by at most 2^-24 p, so a row-dot with PSSM row j moves by at most
+    2^-24 sum_c p_c |P_jc| <= 2^-24 max_c |P_jc|, and a window by the sum over its rows.  Only FINITE cells count: a
+    row-dot that meets a +-inf / NaN cell (p_c > 0 there, or 0 x inf) is replaced by nan_to_num identically in either
+    storage -- float32 keeps exact zeros and the sign of every entry above 1.2e-38."""
+    worst = 0.0
+    for pm in struct_pssm.values():
+        P = np.asarray(pm.matrix(list(pm.keys())), dtype=np.float64)
+        fin = np.where(np.isfinite(P), np.abs(P), 0.0)
+        worst = max(worst, float(fin.max(axis=1).sum()) * 2.0 ** -24)
+    return worst
+
+
+def pick_profile_dtype(requested, struct_pssm):
+    """device storage of averaged-structure profile rows: what was asked for, or -- ``auto`` -- float32 when the PFM at
+    hand PROVES it within FLOAT32_STORAGE_BUDGET (float32_storage_bound), else float64.  -> (numpy type, bound)"""
+    bound = float32_storage_bound(struct_pssm)
+    if requested in ("float32", "float64"):
+        return np.dtype(requested).type, bound
+    return (np.float32 if bound < FLOAT32_STORAGE_BUDGET else np.float64), bound
+
+
 def _scan_profile_stream(engine, stream, ids, letters, pssm, minscore, pairing, columns=False):
     """hit table of a packed profile stream (no codes): rnascan.py:302-315 for every record.  A library (several
     motifs, pfmutil.py:89-133) with a finite threshold is ONE pass per PFM width over the profile (k_profile_lib),
@@ -494,7 +521,13 @@ def scan_combined(engine, records, named_profiles, seq_pssm, struct_pssm, minsco
         batch = _RnaBatch(records)
         if pairs_m and len(batch) and list(batch.ids) == list(pids) and len(set(pids)) == len(pids) and \
                 np.array_equal(batch.lengths, pst.lengths):
-            prof = pst.profile if pst.profile.dtype == np.dtype(profile_dtype) else np.asarray(pst.profile, dtype=profile_dtype)
+            prof = pst.profile
+            if prof.dtype == np.float64 and np.dtype(profile_dtype) == np.float32:
+                # a real downcast (float64 store, float32 rows asked for): one host copy of the batch -- callers keep such
+                # batches at one RNASCAN_BATCH_POSITIONS (cli.store_batches)
+                prof = np.asarray(prof, dtype=np.float32)
+            # a float32 store under float64 rows is scanned AS IT IS: the kernels widen the rows themselves, a float64 copy
+            # of the batch (up to 30 GB at 32 x RNASCAN_BATCH_POSITIONS) would change no score and would leave the mapped file
             stream = pack.Stream(batch.codes, prof, batch.offsets, batch.lengths)
             return _scan_combined_stream(engine, stream, batch, list(letters0), pairs_m, seq_pssm, struct_pssm, minscore, pairing,
                                          columns)

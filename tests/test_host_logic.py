@@ -289,3 +289,64 @@ def test_letter_lut_keeps_the_case_in_bit_3():
     assert np.array_equal(plain, np.where(lut == pack.SEP, pack.SEP, lut & 7))
     codes = pack.encode_letters("EeLlXm", "EHTBLRM", keep_case=True)
     assert codes.tolist() == [0, 8, 4, 12, 7, 14]
+
+
+def _struct_scores(prof, P):
+    """rnascan.py:302-307 in numpy: per-row dot, nan_to_num, sequential fp64 sum"""
+    m = P.shape[0]
+    n = prof.shape[0] - m + 1
+    out = np.zeros(n)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for j in range(m):
+            out = out + np.nan_to_num((prof[j:j + n].astype(np.float64) * P[j]).sum(axis=1))
+    return out
+
+
+def test_float32_storage_bound_holds_against_brute_force():
+    """scanner.float32_storage_bound is a PROVEN bound: on random structure PFMs (with -inf cells too) and profiles whose
+    rows sum to 1 (exact zeros, entries just above powers of two -- the worst case for a relative rounding error) the
+    scores from float32-rounded rows never differ by more than it from the float64 ones"""
+    from collections import OrderedDict
+    from rnascan_amd import scanner
+    rng = np.random.default_rng(17)
+    worst_ratio = 0.0
+    for trial in range(40):
+        m = int(rng.integers(1, 24))
+        counts = rng.dirichlet(np.full(7, rng.choice([0.3, 1.0, 5.0])), size=m)
+        if trial % 3 == 0:
+            counts[rng.random((m, 7)) < 0.15] = 0.0
+        pc = float(rng.choice([0.0, 0.01, 0.5]))
+        pm = pssm.PSSM(pack.STRUCT_LETTERS, pssm.log_odds(pssm.normalize(OrderedDict((l, counts[:, k]) for k, l in enumerate(pack.STRUCT_LETTERS)), pc), None))
+        bound = scanner.float32_storage_bound({"x": pm})
+        P = pm.matrix(list(pack.STRUCT_LETTERS))
+        prof = rng.dirichlet(np.full(7, 0.3), size=4000)
+        prof[prof < 0.02] = 0.0
+        prof[::7] = np.nextafter(np.float32(0.5), np.float32(1.0)) * np.eye(7)[rng.integers(0, 7, size=prof[::7].shape[0])]   # p just above 1/2
+        prof /= np.maximum(prof.sum(axis=1, keepdims=True), 1.0)                    # rows sum to at most 1
+        a, b = _struct_scores(prof, P), _struct_scores(prof.astype(np.float32), P)
+        ok = np.isfinite(a) & (np.abs(a) < 1e300)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~ok & ~np.isnan(a)], b[~ok & ~np.isnan(a)])
+        err = np.abs(a[ok] - b[ok]).max(initial=0.0)
+        assert err <= bound * (1 + 1e-9) + 1e-13, (trial, err, bound)
+        worst_ratio = max(worst_ratio, err / bound if bound else 0.0)
+    assert worst_ratio > 0.02           # and it is not absurdly loose: some case comes within 50x of it
+
+
+def test_profile_dtype_is_picked_from_the_pfm(capsys):
+    """auto: float32 rows only when the structure PFM proves the storage error below 5e-7; the reference's own w = 18
+    example does not (its measured float32 error is 8.6e-7), a flat PFM does; the flag still overrides"""
+    import argparse
+    from collections import OrderedDict
+    from rnascan_amd import cli, scanner
+    slbp = pssm.load_pssms(os.path.join(DATA_DIR, "SLBP_pfm_assembled_normalized_struct.txt"), 0.0, fasta.STRUCT, None)
+    t, bound = scanner.pick_profile_dtype("auto", slbp)
+    assert t is np.float64 and bound > 8.6e-7              # the bound covers what tests/test_gpu_parity.py measures on that example
+    flat = OrderedDict((l, np.full(6, 1.0 / 7) + 0.004 * k) for k, l in enumerate(pack.STRUCT_LETTERS))
+    pm = {"flat": pssm.PSSM(pack.STRUCT_LETTERS, pssm.log_odds(pssm.normalize(flat, 0.0), None))}
+    t, bound = scanner.pick_profile_dtype("auto", pm)
+    assert t is np.float32 and bound < 5e-7
+    assert scanner.pick_profile_dtype("float64", pm)[0] is np.float64 and scanner.pick_profile_dtype("float32", slbp)[0] is np.float32
+    args = argparse.Namespace(profile_dtype="auto")
+    assert cli.profile_type(args, slbp) is np.float64 and cli.profile_type(args, slbp) is np.float64
+    err = capsys.readouterr().err
+    assert err.count("stored as float64") == 1 and "could cost up to" in err      # announced once

@@ -415,3 +415,51 @@ def test_motif_loops_say_that_they_rescan_the_stream():
     del seen[:]
     scanner.scan_profiles(Spy(), named, lib([6, 7, 8]), -6.0)          # three widths: three single-motif scans of one stream
     assert seen == [False, False, False]
+
+
+def test_float32_store_under_float64_rows_is_scanned_in_place(tmp_path):
+    """a float32 packed store whose records sit in FASTA order, under the default (float64) rows: the batch the engine gets
+    IS the mapped file (no float64 copy of up to 32 x RNASCAN_BATCH_POSITIONS rows), and the table equals the float64-copy
+    one -- widening float32 rows changes no score.  A float64 store under float32 rows is a real downcast: one copy."""
+    from rnascan_amd import store
+    rng = np.random.default_rng(8)
+    d = tmp_path / "avg"
+    d.mkdir()
+    fa = tmp_path / "s.fa"
+    with open(fa, "w") as f:
+        for i in range(9):
+            L = int(rng.integers(30, 200))
+            f.write(">r%d\n%s\n" % (i, "".join(rng.choice(list("ACGU"), size=L))))
+            prof = rng.dirichlet(np.full(7, 0.3), size=L)
+            with open(d / ("structure.r%d.txt" % i), "w") as g:
+                g.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+                for k, row in enumerate(prof):
+                    g.write(str(k) + "\t" + "\t".join(str(float(x)) for x in row) + "\n")
+
+    class Spy(OracleEngine):
+        seen = []
+
+        def hits(self, stream, *a, **k):
+            Spy.seen.append(stream.profile)
+            return OracleEngine.hits(self, stream, *a, **k)
+
+    sp = {"s": pssm.pfm2pssm(SEQ_PFM, 0.01, fasta.RNA, None)}
+    tp = {"t": pssm.pfm2pssm(STRUCT_PFM, 0.01, fasta.STRUCT, None)}
+    recs = fasta.LazyFasta(str(fa))
+    tables = {}
+    for sdtype in (np.float32, np.float64):
+        sdir = str(tmp_path / ("store_%s" % np.dtype(sdtype).name))
+        store.build_store(str(d), sdir, sdtype)
+        ps = store.ProfileStore(sdir)
+        order = [ps.ids.index(i) for i in recs.ids]
+        assert order == sorted(order)                       # r0..r8 sort like the FASTA
+        for rows in (np.float32, np.float64):
+            Spy.seen = []
+            pre = (list(recs.ids), ps.letters, ps.stream(0, len(ps.ids)))
+            df = scanner.scan_combined(Spy(), recs[0:len(recs)], None, sp, tp, -25.0, "aligned", rows, prepacked=pre)
+            assert len(df) > 5 and len(Spy.seen) == 1
+            in_place = np.shares_memory(Spy.seen[0], ps.profile)
+            assert in_place == (not (sdtype is np.float64 and rows is np.float32)), (sdtype, rows)
+            tables[(sdtype, rows)] = df
+    pd.testing.assert_frame_equal(tables[(np.float32, np.float32)], tables[(np.float32, np.float64)])
+    pd.testing.assert_frame_equal(tables[(np.float32, np.float32)], tables[(np.float64, np.float32)])
