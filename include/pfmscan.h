@@ -371,6 +371,11 @@ int pfmscan_set_upload_mode(pfmscan_ctx *ctx, int mode);
  * are the same either way.  length == 0 (path may be NULL) forgets the range: do that BEFORE unmapping it.  At most 8
  * ranges per context; a ninth replaces the oldest. */
 int pfmscan_upload_source_file(pfmscan_ctx *ctx, const void *base, size_t length, const char *path, int64_t file_offset);
+/* The same, for a caller that recorded fstat's st_dev / st_ino / st_size of the file WHEN IT MAPPED IT: the range is only
+ * registered when `path` still names that file (a store re-packed by atomic rename in the meantime would otherwise be
+ * read in the mapping's place); PFMSCAN_E_BADARG otherwise, and uploads keep reading the mapping. */
+int pfmscan_upload_source_file_checked(pfmscan_ctx *ctx, const void *base, size_t length, const char *path,
+                                       int64_t file_offset, int64_t st_dev, int64_t st_ino, int64_t st_size);
 
 /* ---- host ingest and output (no device needed; no context: errors via pfmscan_last_error(NULL)) ---------------
  * The two pieces of host work that dwarf the kernel at scale, in native code.
@@ -387,6 +392,10 @@ int pfmscan_upload_source_file(pfmscan_ctx *ctx, const void *base, size_t length
  * pfmscan_fasta_encode: records [lo, hi) -> codes[sum(n_letters + 1)]: lut256[byte] per letter, `separator`
  *   after each record (stream layout above); offsets[i] = stream position of record lo + i.  n_threads <= 0:
  *   as many as the host offers, at most 16. */
+/* pfmscan_fasta_lone_cr: *found = 1 when buf holds a carriage return that is not followed by a line feed (old-Mac line
+ * ends: the reference's universal-newline reader breaks lines there, pfmscan_fasta_index at \n only -- the caller
+ * parses such a file the slow way).  One parallel pass at memory speed over the WHOLE buffer. */
+int pfmscan_fasta_lone_cr(const uint8_t *buf, int64_t n, int *found, int n_threads);
 int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t *hdr_off,
                         int64_t *hdr_len, int64_t *seq_off, int64_t *seq_end, int64_t *n_letters,
                         int64_t *n_records, int n_threads);

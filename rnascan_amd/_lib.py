@@ -37,7 +37,7 @@ SYMBOLS = [
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
     "pfmscan_hits_pair_dev", "pfmscan_stage_codes2", "pfmscan_hits_pair_staged", "pfmscan_hits_pair_host", "pfmscan_round_decimals",
-    "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
+    "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_upload_source_file_checked", "pfmscan_fasta_lone_cr", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -130,6 +130,8 @@ def load():
     L.pfmscan_debug_credit8_table.argtypes = [vp, i32, dbl, vp, ctypes.POINTER(i32)]
     L.pfmscan_set_upload_mode.argtypes = [vp, i32]
     L.pfmscan_upload_source_file.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64]
+    L.pfmscan_upload_source_file_checked.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64, i64, i64, i64]
+    L.pfmscan_fasta_lone_cr.argtypes = [vp, i64, ctypes.POINTER(i32), i32]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
@@ -213,6 +215,17 @@ def fasta_index(buf, threads=0):
         if rc != OK:
             _raise(L, None, rc)
         return tuple(c[:n.value] for c in cols)
+
+
+def fasta_lone_cr(buf, threads=0):
+    """True when the FASTA bytes hold a carriage return that is not part of \\r\\n (anywhere in the buffer)"""
+    L = load()
+    buf = np.asarray(buf)
+    found = ctypes.c_int(0)
+    rc = L.pfmscan_fasta_lone_cr(_ptr(buf), buf.size, ctypes.byref(found), int(threads))
+    if rc != OK:
+        _raise(L, None, rc)
+    return bool(found.value)
 
 
 def fasta_ids(buf, hdr_off, hdr_len):
@@ -508,7 +521,17 @@ class Context(object):
         base = mm.ctypes.data
         if base in known:
             return
-        rc = self._L.pfmscan_upload_source_file(self._h, ctypes.c_void_p(base), mm.nbytes, os.fsencode(str(mm.filename)), int(mm.offset))
+        # which file was mapped: recorded by whoever opened the memmap (store.ProfileStore), else taken now -- the checked
+        # form refuses a path that has come to name another file since (a re-packed store), uploads then read the mapping
+        ident = getattr(mm, "_mapped_file_id", None)
+        if ident is None:
+            try:
+                st = os.stat(mm.filename)
+                ident = (st.st_dev, st.st_ino, st.st_size)
+            except OSError:
+                return
+        rc = self._L.pfmscan_upload_source_file_checked(self._h, ctypes.c_void_p(base), mm.nbytes, os.fsencode(str(mm.filename)),
+                                                        int(mm.offset), int(ident[0]), int(ident[1]), int(ident[2]))
         if rc:
             return                                      # not fatal: the mapping itself is still a valid source
         ctx_ref = weakref.ref(self)

@@ -214,6 +214,26 @@ void index_piece(const uint8_t *buf, int64_t n, int64_t from, int64_t to, bool c
 
 extern "C" {
 
+int pfmscan_fasta_lone_cr(const uint8_t *buf, int64_t n, int *found, int n_threads)
+{
+    if ((!buf && n > 0) || n < 0 || !found) return fail(nullptr, PFMSCAN_E_BADARG, "fasta_lone_cr: bad argument");
+    const int threads = pick_threads(n_threads, n >> 22);
+    std::vector<int> hit((size_t)threads, 0);
+    parallel_ranges(n, threads, [&](int t, int64_t a, int64_t b) {
+        const uint8_t *q = buf + a, *const end = buf + b;
+        while (q < end && (q = static_cast<const uint8_t *>(std::memchr(q, '\r', (size_t)(end - q)))) != nullptr) {
+            if (q + 1 >= buf + n || q[1] != '\n') {          // (the byte after a piece's last one belongs to the next piece: still in buf)
+                hit[(size_t)t] = 1;
+                return;
+            }
+            ++q;
+        }
+    });
+    *found = 0;
+    for (int h : hit) *found |= h;
+    return PFMSCAN_OK;
+}
+
 int pfmscan_fasta_index(const uint8_t *buf, int64_t n, int64_t capacity, int64_t *hdr_off, int64_t *hdr_len,
                         int64_t *seq_off, int64_t *seq_end, int64_t *n_letters, int64_t *n_records, int n_threads)
 {

@@ -8,6 +8,7 @@
 // in-place pinning already reaches the PCIe rate), so the staged path is a MODE the caller selects for sources it knows
 // to be file mappings (pfmscan_set_upload_mode; rnascan_amd/_lib.py does it for numpy memmaps).
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -214,7 +215,16 @@ extern "C" int pfmscan_set_upload_mode(pfmscan_ctx *ctx, int mode)
     return PFMSCAN_OK;
 }
 
+extern "C" int pfmscan_upload_source_file_checked(pfmscan_ctx *ctx, const void *base, size_t length, const char *path,
+                                                  int64_t file_offset, int64_t st_dev, int64_t st_ino, int64_t st_size);
+
 extern "C" int pfmscan_upload_source_file(pfmscan_ctx *ctx, const void *base, size_t length, const char *path, int64_t file_offset)
+{
+    return pfmscan_upload_source_file_checked(ctx, base, length, path, file_offset, -1, -1, -1);
+}
+
+extern "C" int pfmscan_upload_source_file_checked(pfmscan_ctx *ctx, const void *base, size_t length, const char *path,
+                                                  int64_t file_offset, int64_t st_dev, int64_t st_ino, int64_t st_size)
 {
     if (!ctx || !base) return pfmscan::fail(ctx, PFMSCAN_E_BADARG, "pfmscan_upload_source_file: NULL argument");
     const unsigned char *b = static_cast<const unsigned char *>(base);
@@ -227,6 +237,15 @@ extern "C" int pfmscan_upload_source_file(pfmscan_ctx *ctx, const void *base, si
     if (!path || file_offset < 0) return pfmscan::fail(ctx, PFMSCAN_E_BADARG, "pfmscan_upload_source_file: no path / negative offset");
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return pfmscan::fail(ctx, PFMSCAN_E_BADARG, std::string("pfmscan_upload_source_file: cannot open ") + path);
+    if (st_ino >= 0) {
+        // the caller recorded which file it MAPPED: a path that now names another file (a store re-packed by atomic rename
+        // since) must not be pread in the mapping's place -- the mapping itself stays a valid source
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || (int64_t)sb.st_dev != st_dev || (int64_t)sb.st_ino != st_ino || (int64_t)sb.st_size != st_size) {
+            (void)close(fd);
+            return pfmscan::fail(ctx, PFMSCAN_E_BADARG, std::string("pfmscan_upload_source_file: ") + path + " is not the file that was mapped any more");
+        }
+    }
     pfmscan_ctx::FileRange *slot = nullptr;
     for (pfmscan_ctx::FileRange &fr : ctx->file_ranges)
         if (fr.fd < 0 && !slot) slot = &fr;

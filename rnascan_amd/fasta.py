@@ -174,21 +174,6 @@ class FastaSlice(object):
         return self.parent._pack(self.lo, self.hi, lut)
 
 
-def _has_lone_cr(path, probe=1 << 20):
-    """True when the file's first MiB holds a carriage return that is not part of \\r\\n: universal newlines make it a
-    line end, the native FASTA index would not.  A file written with CR-only line ends (old Mac) has them from the first
-    line on, so the head of the file decides (scanning all of a 300 MB FASTA for a stray \\r cost as much as indexing and
-    packing it)."""
-    with open(path, "rb") as fh:
-        head = fh.read(probe + 1)
-    at = head.find(b"\r")
-    while 0 <= at < min(len(head), probe):
-        if head[at + 1:at + 2] != b"\n":
-            return True
-        at = head.find(b"\r", at + 1)
-    return False
-
-
 class LazyFasta(object):
     """A FASTA file as a sliceable sequence of Records that holds only an INDEX in memory: header location, byte range
     and letter count per record, from one native pass over the mapped bytes (``pfmscan_fasta_index``).  ``lazy[a:b]``
@@ -209,7 +194,19 @@ class LazyFasta(object):
         self._parsed = {}                      # global record index -> Record (compressed files)
         file_of, local_of, lengths = [], [], []
         for fi, path in enumerate(self.files):
-            if os.path.splitext(path)[1] in (".gz", ".bz2") or _has_lone_cr(path):
+            mm = buf = None
+            if os.path.splitext(path)[1] not in (".gz", ".bz2"):
+                if os.path.getsize(path):
+                    with open(path, "rb") as fh:
+                        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                    buf = np.frombuffer(mm, dtype=np.uint8)
+                    # a carriage return that is not part of \r\n ANYWHERE in the file (one native pass at memory speed):
+                    # universal newlines make it a line end, the native index would not -- such a file is parsed instead
+                    if _lib.fasta_lone_cr(buf):
+                        mm = buf = None
+                else:
+                    mm, buf = b"", np.zeros(0, dtype=np.uint8)
+            if buf is None:
                 self._maps.append(None)
                 self._bufs.append(None)
                 self._index.append(None)
@@ -221,12 +218,6 @@ class LazyFasta(object):
                 local_of.append(np.arange(len(recs), dtype=np.int64))
                 lengths.append(np.array([len(r.seq) for r in recs], dtype=np.int64))
                 continue
-            if os.path.getsize(path):
-                with open(path, "rb") as fh:
-                    mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
-                buf = np.frombuffer(mm, dtype=np.uint8)
-            else:
-                mm, buf = b"", np.zeros(0, dtype=np.uint8)
             idx = _lib.fasta_index(buf)
             self._maps.append(mm)
             self._bufs.append(buf)

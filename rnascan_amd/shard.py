@@ -116,8 +116,16 @@ SPOOL_BLOCK = 32 << 20
 def open_spool():
     """a rank's row spool: a temporary file (RNASCAN_SPOOL_DIR, else the system's) that rank 0 reads back; text mode over
     a byte stream, like stdout, so that the TSV writer takes its zero-copy path"""
+    import atexit
     import tempfile
     fd, path = tempfile.mkstemp(prefix="rnascan_rows_", suffix=".tsv", dir=os.environ.get("RNASCAN_SPOOL_DIR") or None)
+
+    def drop(path=path):                       # a rank that dies before the relay (launch.py ends the others) leaves no spool behind
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    atexit.register(drop)
     return os.fdopen(fd, "w", encoding="utf-8", newline=""), path
 
 
@@ -129,6 +137,9 @@ def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
     over the process group in blocks instead.  Returns the next free id on rank 0 (None elsewhere)."""
     import torch
     from . import _lib
+    # the blocks of the send path are tensors of the process group's backend: NCCL (RCCL) moves device memory only
+    nccl = getattr(dist, "get_backend", lambda: "gloo")() == "nccl"
+    where = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
     infos = [None] * world if rank == 0 else None
     dist.gather_object((my_path, int(my_rows)), infos, dst=0)
     readable = [None]
@@ -142,10 +153,10 @@ def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
             with open(my_path, "rb") as f:
                 while True:
                     block = f.read(SPOOL_BLOCK)
-                    dist.send(torch.tensor([len(block)], dtype=torch.int64), dst=0)
+                    dist.send(torch.tensor([len(block)], dtype=torch.int64, device=where), dst=0)
                     if not block:
                         break
-                    dist.send(torch.frombuffer(bytearray(block), dtype=torch.uint8), dst=0)
+                    dist.send(torch.frombuffer(bytearray(block), dtype=torch.uint8).to(where), dst=0)
         dist.barrier()                                     # rank 0 is done with the file
         if my_path and os.path.exists(my_path):
             os.unlink(my_path)
@@ -180,13 +191,13 @@ def relay_spools(out, first_id, my_path, my_rows, rank, world, dist):
                         break
                     state = emit(block, state)
         else:
-            size = torch.zeros(1, dtype=torch.int64)
+            size = torch.zeros(1, dtype=torch.int64, device=where)
             while True:
                 dist.recv(size, src=r)
                 if int(size[0]) == 0:
                     break
-                buf = torch.empty(int(size[0]), dtype=torch.uint8)
+                buf = torch.empty(int(size[0]), dtype=torch.uint8, device=where)
                 dist.recv(buf, src=r)
-                state = emit(buf.numpy().tobytes(), state)
+                state = emit(buf.cpu().numpy().tobytes(), state)
     dist.barrier()
     return next_id

@@ -77,8 +77,12 @@ class ProfileStore(object):
         self.lengths = np.asarray(idx["lengths"], dtype=np.int64)
         self.dtype = np.dtype(idx["dtype"])
         self.n_pos = int(idx["n_pos"])
-        self.profile = np.memmap(os.path.join(store_dir, idx["file"]), dtype=self.dtype, mode="r",
-                                 shape=(self.n_pos, 7))
+        with open(os.path.join(store_dir, idx["file"]), "rb") as fh:
+            st = os.fstat(fh.fileno())
+            self.profile = np.memmap(fh, dtype=self.dtype, mode="r", shape=(self.n_pos, 7))
+        # WHICH file is mapped (the path may come to name another one: a store re-packed by rename while this one is open);
+        # the staged uploader reads the file beside the mapping only while the path still names this file (_lib._register_mapping)
+        self.profile._mapped_file_id = (st.st_dev, st.st_ino, st.st_size)
         self.offsets = np.zeros(len(self.lengths), dtype=np.int64)
         if len(self.lengths) > 1:
             self.offsets[1:] = np.cumsum(self.lengths[:-1] + 1)

@@ -441,3 +441,41 @@ def test_staged_upload_reads_the_file_behind_a_mapping(ctx, tmp_path, monkeypatc
     gc.collect()
     assert len(ctx._mappings) == before                       # forgotten before the mapping went away
     motif.close()
+
+
+def test_a_repacked_store_is_not_read_in_the_mapping_place(ctx, tmp_path, monkeypatch):
+    """the staged uploader preads the FILE a read-only memmap maps -- but only while the path still names that file.  A
+    store re-packed by rename after it was opened (same path, other bytes): the registration is refused, the upload reads
+    the mapping, the hits are those of the bytes that were mapped."""
+    import ctypes
+    from rnascan_amd import _lib, store
+    from test_gpu_parity import rand_struct_pssm
+    rng = np.random.default_rng(4)
+    sdir = tmp_path / "st"
+    d = tmp_path / "avg"
+    d.mkdir()
+    L = 3000
+    for i in range(4):
+        prof = rng.dirichlet(np.full(7, 0.3), size=L)
+        with open(d / ("structure.r%d.txt" % i), "w") as g:
+            g.write("PO\t" + "\t".join("BEHLMRT") + "\n")
+            g.writelines(str(k) + "\t" + "\t".join(str(float(x)) for x in row) + "\n" for k, row in enumerate(prof))
+    store.build_store(str(d), str(sdir), np.float32)
+    ps = store.ProfileStore(str(sdir))
+    mapped = np.array(ps.profile)                             # the bytes that are mapped
+    assert ps.profile._mapped_file_id[1] == os.stat(sdir / "profile.f32").st_ino
+    # same path, another file (what an atomic re-pack does): other rows
+    other = np.ascontiguousarray(mapped[::-1])
+    tmp = sdir / "profile.f32.new"
+    other.tofile(tmp)
+    os.replace(tmp, sdir / "profile.f32")
+    L_ = _lib.load()
+    rc = L_.pfmscan_upload_source_file_checked(ctx._h, ctypes.c_void_p(ps.profile.ctypes.data), ps.profile.nbytes,
+                                               os.fsencode(str(sdir / "profile.f32")), 0, *[int(x) for x in ps.profile._mapped_file_id])
+    assert rc == _lib.E_BADARG and b"not the file that was mapped" in L_.pfmscan_last_error(ctx._h)
+    motif = ctx.motif(None, rand_struct_pssm(rng, 10, inf_frac=0.0))
+    monkeypatch.setenv("PFMSCAN_UPLOAD", "1")                 # force the staged path for this small store
+    got = ctx.hits_host(motif, None, ps.profile, -np.inf, -3.0)
+    want = ctx.hits_host(motif, None, mapped, -np.inf, -3.0)
+    assert len(want[0]) > 100 and np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    motif.close()

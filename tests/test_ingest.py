@@ -116,8 +116,18 @@ def test_cr_only_line_ends_take_the_record_path(tmp_path):
     assert list(lz.lengths) == [8, 2]
     q = tmp_path / "dos.fa"
     q.write_bytes(b">b first\r\nACGU\r\nACGU\r\n")
-    assert not fasta._has_lone_cr(str(q)) and fasta._has_lone_cr(str(p))
+    as_bytes = lambda path: np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    assert not _lib.fasta_lone_cr(as_bytes(q)) and _lib.fasta_lone_cr(as_bytes(p))
     assert [(r.id, r.seq) for r in fasta.LazyFasta(str(q))[0:1]] == [("b", "ACGUACGU")]
+    # the WHOLE file is looked at (natively, in parallel pieces): one lone \r after 40 MB of \n / \r\n lines is found,
+    # also as the very last byte and right at a piece boundary's \r\n
+    big = tmp_path / "late.fa"
+    body = b">r\nACGUACGUACGUACGUACGUACGUACGUACGUACGUACGU\r\nACGU\n" * 700000
+    big.write_bytes(body + b">x\nAC\rGU\n")
+    assert _lib.fasta_lone_cr(as_bytes(big)) and fasta.LazyFasta(str(big))._index[0] is None
+    assert fasta.LazyFasta(str(big))[700000].seq == "ACGU"
+    assert not _lib.fasta_lone_cr(np.frombuffer(body, dtype=np.uint8))
+    assert _lib.fasta_lone_cr(np.frombuffer(body + b"\r", dtype=np.uint8)) and not _lib.fasta_lone_cr(np.zeros(0, dtype=np.uint8))
 
 
 def test_fasta_index_argument_errors():
@@ -399,3 +409,17 @@ def test_ingest_under_sanitizers(tmp_path):
     assert built.returncode == 0, built.stderr[-2000:]
     run = subprocess.run([exe, "4000"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and run.stdout.strip().startswith("ok"), (run.stdout + run.stderr)[-3000:]
+
+
+def test_staged_upload_source_must_still_be_the_mapped_file(tmp_path):
+    """pfmscan_upload_source_file_checked: the path is pread in the mapping's place only while it names the file that was
+    mapped (st_dev / st_ino / st_size recorded at mapping time) -- a store re-packed by rename is refused.  The check sits
+    in front of any device work, so it runs without a GPU on a NULL context: BADARG either way, the message tells which."""
+    import ctypes
+    L = _lib.load()
+    p = tmp_path / "rows.bin"
+    p.write_bytes(b"x" * 4096)
+    st = os.stat(p)
+    buf = np.zeros(4096, dtype=np.uint8)
+    rc = L.pfmscan_upload_source_file_checked(None, buf.ctypes.data_as(ctypes.c_void_p), 4096, os.fsencode(str(p)), 0, st.st_dev, st.st_ino, st.st_size)
+    assert rc == _lib.E_BADARG                     # no context: refused before the file is looked at
