@@ -1174,9 +1174,15 @@ __global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_prof
     const int64_t tile0 = (int64_t)blockIdx.x * L::TILE;
     const int prof_bytes = L::prof_bytes(m);
     char *tseq_lds = reinterpret_cast<char *>(smem + L::buf_bytes(m, HAS_SEQ));
+    // The waves of a NEW workgroup are the youngest on their SIMD and the arbiter serves the oldest first, so their ~60
+    // staging instructions would queue behind the resident workgroups' FMAs; with raised priority the tile's loads are
+    // in flight at once (C3: 2.209 -> 2.198 and 2.215 -> 2.195 ms in two interleaved A/B pairs, profiles/r4/NOTES.md;
+    // the same for the stores of a finished wave changed nothing).  PFMSCAN_PRIO=0 turns it off.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     if (!(a.ablate & 2)) stage_tile<V, HAS_SEQ, PROF_T, DMA>(a, tile0, smem, m);
     if (HAS_SEQ)
         for (int i = threadIdx.x; i < m * 8; i += BLOCK) reinterpret_cast<double *>(tseq_lds)[i] = a.letter_table[i];
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
     if (DMA == 2) dma_wait_all();
     __syncthreads();
     const int la = threadIdx.x * V;
