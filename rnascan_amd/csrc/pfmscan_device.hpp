@@ -10,6 +10,7 @@ namespace pfmscan {
 constexpr int BLOCK = 256;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 // k_letters: a workgroup scores ITERS x 1024 windows (fewer for the widest PFM bucket, whose
@@ -47,6 +48,20 @@ template <int TILE> struct CodeStage {
     u32x4 r[PER];
     __device__ __forceinline__ void fetch(const uint8_t *__restrict__ codes, int64_t tile0, int64_t n_pos)
     {
+        if (tile0 + TILE + CODE_HALO <= n_pos) {
+            // the tile and its halo lie inside the stream (workgroup-uniform: tile0 comes from blockIdx): plain vector
+            // loads off one base, no per-lane 64-bit bounds tests (they were ~20 VALU instructions per lane and tile of
+            // the tile-walking hits kernels, whose whole prefilter is ~80 per lane and tile)
+            const u32x4 *__restrict__ src = reinterpret_cast<const u32x4 *>(codes + tile0);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + k * BLOCK;
+                u32x4 v = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
+                if ((k + 1) * BLOCK <= NVEC || i < NVEC) v = src[i];
+                r[k] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * BLOCK;

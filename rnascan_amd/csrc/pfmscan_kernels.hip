@@ -574,27 +574,35 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
                 if (wi >= -2 && wi <= W - 1) pk[wi + 2] += dj[j];
             }
         }
-        uint32_t sum[W];
-        uint32_t any = 0;
+        // The 16 sums two at a time: with A = P[w], B = P[w-2], C = P[w+2] one v_alignbit + one v_pk_add_u16 give
+        // (sum(w) << 16 | sum(w+2)); bit 15 of a sum (they stay below 2^16) is its flag.  `surv` collects the flags of the
+        // pair k = 0..7 -- windows 4 (k >> 1) + (k & 1) and that + 2 -- at bits 24 + k and 8 + k: two VALU instructions
+        // per window in all, hits or not.
+        uint32_t surv = 0;
 #pragma unroll
-        for (int v = 0; v < W; ++v) {
-            sum[v] = (pk[v + 2] >> 16) + (pk[v] & 0xFFFFu);
-            any |= sum[v];
+        for (int k = 0; k < 8; ++k) {
+            const int w = 4 * (k >> 1) + (k & 1);
+            const uint32_t x = __builtin_amdgcn_alignbit(pk[w], pk[w + 4], 16);       // lo(P[w-2]) << 16 | hi(P[w+2])
+            const u16x2 r = __builtin_bit_cast(u16x2, pk[w + 2]) + __builtin_bit_cast(u16x2, x);
+            surv = (surv >> 1) | (__builtin_bit_cast(uint32_t, r) & 0x80008000u);
         }
-        // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes and score NaN later)
-        if (__builtin_amdgcn_ballot_w64((any & 0x8000u) != 0)) {
-#pragma unroll
-            for (int v = 0; v < W; ++v) {
-                const bool sv = (sum[v] & 0x8000u) != 0;
-                const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
-                if (sb) {                               // wave-uniform
-                    if (sv) my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
-                    sv_n += __popcll(sb);
-                    if (sv_n >= 64) {                   // the top 64 get their exact score, the rest stays
-                        exact_batch(sv_n - 64, 64);
-                        sv_n -= 64;
-                    }
-                }
+        // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes and score NaN later).  ONE
+        // rolled loop, every pass each lane that still has a survivor hands over its lowest one: at -m 6 a sixth of the
+        // (wave, window slot) pairs holds a survivor, and the unrolled pass per slot (test, ballot, branch, push) cost
+        // 3.3 of the kernel's 12.3 VALU instructions per window; this form 1.1 + the two above
+        while (__builtin_amdgcn_ballot_w64(surv != 0)) {
+            const bool sv = surv != 0;
+            const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
+            if (sv) {
+                const int b = __builtin_ctz(surv);
+                surv &= surv - 1;
+                const int k = b & 7, v = 4 * (k >> 1) + (k & 1) + (b < 16 ? 2 : 0);
+                my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
+            }
+            sv_n += __popcll(sb);
+            if (sv_n >= 64) {                           // the top 64 get their exact score, the rest stays
+                exact_batch(sv_n - 64, 64);
+                sv_n -= 64;
             }
         }
 

@@ -203,12 +203,15 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
                 if (u >= 0 && u <= W) pk[u] += dj[k];
             }
         }
-        // bit v of `surv` = window v of this lane may be a hit
+        // The 16 sums two at a time: with A = P[w+1] one v_alignbit (lo(P[w]) << 16 | hi(P[w+2])) + one v_pk_add_u16 give
+        // (sum(w) << 16 | sum(w+1)); bit 15 of a sum (they stay below 2^16) is its flag.  `surv` collects the flags of the
+        // pair k = 0..7 (windows 2k and 2k + 1) at bits 24 + k and 8 + k: two VALU instructions per window, hits or not.
         uint32_t surv = 0;
 #pragma unroll
-        for (int v = 0; v < W; ++v) {
-            const uint32_t sum = (pk[v] & 0xFFFFu) + (pk[v + 1] >> 16);
-            surv |= ((sum >> 15) & 1u) << v;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t x = __builtin_amdgcn_alignbit(pk[2 * k], pk[2 * k + 2], 16);
+            const u16x2 r = __builtin_bit_cast(u16x2, pk[2 * k + 1]) + __builtin_bit_cast(u16x2, x);
+            surv = (surv >> 1) | (__builtin_bit_cast(uint32_t, r) & 0x80008000u);
         }
         // Survivors -> the wave's queue (positions only; windows past the end hold SEP codes: no credit).  ONE rolled
         // loop: every pass each lane that still has a survivor hands over its lowest one (an unrolled pass per window
@@ -217,8 +220,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
             const bool sv = surv != 0;
             const unsigned long long sb = __builtin_amdgcn_ballot_w64(sv);
             if (sv) {
-                const int v = __builtin_ctz(surv);
+                const int b = __builtin_ctz(surv);
                 surv &= surv - 1;
+                const int v = 2 * (b & 7) + (b < 16 ? 1 : 0);
                 my_sv[sv_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)(tile0 - first) + (uint32_t)(off0 + v);
             }
             sv_n += __popcll(sb);
