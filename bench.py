@@ -303,6 +303,9 @@ def dry_run(args, world):
     rank = int(os.environ.get("RANK", "0"))
     if os.environ.get("PFMSCAN_BENCH_DRYRUN_FAIL_RANK") == str(rank):
         raise SystemExit(3)                       # the launcher test's failing rank
+    # the shard arithmetic of the real run (weak scaling: fixed work per GPU; C4 = 8 x 125 000 records of 3 kb)
+    records = args.records if args.records is not None else (125000 if world == 8 else 100000)
+    windows = records * (args.length - args.width + 1) * (args.motifs if args.workload in ("c5", "c5s") else 1)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -322,14 +325,26 @@ def dry_run(args, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
         box = [None] * world
-        dist.all_gather_object(box, kernel_ms)
-        rank_ms = box
+        dist.all_gather_object(box, (kernel_ms, records, windows, rank))
+        rank_ms = [b[0] for b in box]
+        assert [b[3] for b in box] == list(range(world))
+        all_windows = sum(b[2] for b in box)
+        all_records = sum(b[1] for b in box)
+    else:
+        all_windows, all_records = windows, records
     result = None
     if rank == 0:
+        shard = "C4: 1M records x 3 kb over 8 GPUs" if (world == 8 and records == 125000 and args.length == 3000) else "%d x %d records" % (world, records)
         result = {"metric": "DRY RUN of the multi-rank launcher (no GPU work, no score computed)", "value": None, "unit": "windows/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none", "dry_run": True,
-                  "config": {"workload": "none (PFMSCAN_BENCH_DRYRUN=1)"}, "per_rank": {"kernel_ms": rank_ms}}
+                  "config": {"workload": "none (PFMSCAN_BENCH_DRYRUN=1); the real run would scan " + shard, "bench_workload": args.workload,
+                             "records_per_gpu": records, "records_all_ranks": all_records, "record_length": args.length,
+                             "pfm_width": args.width, "windows_per_gpu_per_step": windows, "windows_all_ranks_per_step": all_windows,
+                             "sharding": "records, no collective"},
+                  # what `value` is made of in the real run: the units ALL ranks processed / the slowest rank's time
+                  "value_formula": "windows_all_ranks_per_step * steps / (MAX over ranks of the timed region)",
+                  "per_rank": {"kernel_ms": rank_ms}}
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:

@@ -39,6 +39,38 @@ def test_bench_failing_rank_fails_the_parent():
     assert "rank 2 of 3 exited with code 3" in r.stderr
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus_8_dry_run_is_config_4s_sharding():
+    """the shape the driver's 8-GPU run takes (no 8-GPU node can be had here): eight gloo ranks from one command, each
+    with C4's 125 000 records x 3 kb (1M records over the node, rnascan.py:388-395 fans the same records out to -c
+    workers), one JSON line with eight per-rank entries, the windows of ALL ranks in the value's numerator"""
+    r = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"PFMSCAN_BENCH_DRYRUN": "1"}, timeout=500)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["scaling"] == "weak" and len(res["per_rank"]["kernel_ms"]) == 8
+    cfg = res["config"]
+    assert cfg["records_per_gpu"] == 125000 and cfg["records_all_ranks"] == 1000000 and "C4: 1M records" in cfg["workload"]
+    assert cfg["windows_per_gpu_per_step"] == 125000 * 2989 and cfg["windows_all_ranks_per_step"] == 8 * 125000 * 2989
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_8_workload_c5_dry_run_and_a_failing_rank_stops_seven():
+    """config 5's "8 x MI355X" form goes through the same launcher (`bench.py --gpus 8 --workload c5`: every rank scans the
+    256-PFM library over its own records); and when one of eight ranks fails the parent stops the other seven, prints no
+    result line and returns that rank's code"""
+    r = _bench(["--gpus", "8", "--workload", "c5", "--steps", "2", "--warmup", "1"], {"PFMSCAN_BENCH_DRYRUN": "1"}, timeout=500)
+    assert r.returncode == 0, r.stderr
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 8 and res["config"]["bench_workload"] == "c5"
+    assert res["config"]["windows_all_ranks_per_step"] == 8 * 125000 * 2989 * 256           # window-motif pairs of all ranks
+    r = _bench(["--gpus", "8", "--steps", "2"], {"PFMSCAN_BENCH_DRYRUN": "1", "PFMSCAN_BENCH_DRYRUN_FAIL_RANK": "5"}, timeout=500)
+    assert r.returncode == 3
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank 5 of 8 exited with code 3" in r.stderr
+
+
 def test_bench_gpus_must_match_an_outer_launcher():
     r = _bench(["--gpus", "8"], {"PFMSCAN_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
