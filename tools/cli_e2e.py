@@ -19,6 +19,13 @@ with open(fa, "wb") as f:
     for i in range(R):
         f.write(b">t%d transcript %d\n" % (i, i))
         f.write(letters[rng.integers(0, 4, size=L)].tobytes() + b"\n")
+# the structure letter strings of the same records (SS mode and the two-FASTA RNASS mode, rnascan.py:119-133)
+sfa = os.path.join(d, "structs.fa")
+sletters = np.frombuffer(b"EHTBLRM", dtype=np.uint8)
+with open(sfa, "wb") as f:
+    for i in range(R):
+        f.write(b">t%d structure %d\n" % (i, i))
+        f.write(sletters[rng.integers(0, 7, size=L)].tobytes() + b"\n")
 # packed store written directly (the converter's output format), float32
 sd = os.path.join(d, "packed")
 os.makedirs(sd)
@@ -33,12 +40,15 @@ json.dump({"format": 1, "dtype": "float32", "letters": list("BEHLMRT"), "ids": [
            "lengths": [L] * R, "n_pos": R * (L + 1), "file": "profile.f32", "separator_rows": "one zero row after each record"},
           open(os.path.join(sd, "index.json"), "w"))
 big = os.path.join(d, "big.fa")
+bigs = os.path.join(d, "big_structs.fa")
 if RBIG:
-    with open(big, "wb") as f:
+    with open(big, "wb") as f, open(bigs, "wb") as g:
         for lo in range(0, RBIG, 2000):
             n = min(2000, RBIG - lo)
             body = letters[rng.integers(0, 4, size=(n, L))]
             f.write(b"".join(b">t%d transcript %d\n" % (lo + i, lo + i) + body[i].tobytes() + b"\n" for i in range(n)))
+            body = sletters[rng.integers(0, 7, size=(n, L))]
+            g.write(b"".join(b">t%d structure %d\n" % (lo + i, lo + i) + body[i].tobytes() + b"\n" for i in range(n)))
 bigsd = os.path.join(d, "bigpacked")
 if RBIG and BIGSTORE:
     os.makedirs(bigsd)
@@ -66,6 +76,18 @@ runs = [
                                     "-q", os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", " -4",
                                     "--profile-dtype", "float32", fa, sd]),
 ]
+SPFM, TPFM = os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt")
+runs += [("SS: -q pfm structs.fa -m 6", ["-q", TPFM, "-C", "0.01", "-u", sfa]),
+         ("SS: -q pfm structs.fa -m 0", ["-q", TPFM, "-C", "0.01", "-u", "-m", "0", sfa]),
+         ("SS: -q pfm structs.fa, background from the file", ["-q", TPFM, "-C", "0.01", sfa]),
+         ("SS: -q pfm structs.fa -m -inf (every window a row)", ["-q", TPFM, "-C", "0.01", "-u", "-m", " -inf", sfa]),
+         ("RNASS two FASTA: -p -q seqs.fa structs.fa -m 0", ["-p", SPFM, "-q", TPFM, "-C", "0.01", "-u", "-m", "0", fa, sfa]),
+         ("RNASS two FASTA: -m -6", ["-p", SPFM, "-q", TPFM, "-C", "0.01", "-u", "-m", " -6", fa, sfa])]
+if RBIG:
+    runs += [("big: SS -q pfm structs.fa -m 6", ["-q", TPFM, "-C", "0.01", "-u", bigs]),
+             ("big: SS -q pfm structs.fa -m 0", ["-q", TPFM, "-C", "0.01", "-u", "-m", "0", bigs]),
+             ("big: RNASS two FASTA -m 0", ["-p", SPFM, "-q", TPFM, "-C", "0.01", "-u", "-m", "0", big, bigs]),
+             ("big: RNASS two FASTA -m -6", ["-p", SPFM, "-q", TPFM, "-C", "0.01", "-u", "-m", " -6", big, bigs])]
 if RBIG:
     runs += [("big: seq only -m 6", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", big]),
              ("big: seq only -m 2", ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-C", "0.01", "-u", "-m", "2", big])]
