@@ -176,8 +176,13 @@ def library_roofline(info, windows, n_motifs, width, records, length, kernel_ms,
         "nominal_2B_per_credit_frac": nominal / (kernel_ms * 1e-3) / 1e9 / lds_peak,
         "lds_idx_active_frac": pmc.get("lds_idx_active_frac"), "lds_bank_conflict_frac_of_active": pmc.get("lds_bank_conflict_frac"),
         "counter_source": pmc.get("source"),
-        "hbm_frac": (records * length * info["passes"] + (cand or 0) * width * 28 + (n_hits or 0) * 24)
-                    / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # HBM: from the counters of that PMC run (FETCH_SIZE + WRITE_SIZE per step, 1024-byte units; the gathers are 16-byte
+        # loads, for which the gfx950 half-count correction of coalesced streams does not apply) over THIS run's time
+        "hbm_frac": None if not pmc.get("hbm_bytes_per_step") else pmc["hbm_bytes_per_step"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "hbm_frac_source": pmc.get("source"),
+        # what the kernel REQUESTS (codes once per pass + 28 B x w per candidate + the hits): mostly cache hits, NOT HBM traffic
+        "requested_bytes_frac_of_hbm_peak": (records * length * info["passes"] + (cand or 0) * width * 28 + (n_hits or 0) * 24)
+                                            / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "fp64_tflops_of_73_measured": None if cand is None else cand * width * 14 / (kernel_ms * 1e-3) / 1e12,
         "prefilter_slack_score_units": info["max_prefilter_eps"],
     }
@@ -676,6 +681,16 @@ def main():
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
+        if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32":
+            # the same byte mix (29 B in + 12 B out per position) moved by a program that scores nothing
+            # (tools/hbm_mixed.hip, measured on this chip in round 4): what the memory system gives this access pattern
+            floor = pmc_entry("c3_mixed_floor")
+            if floor.get("records") == args.records and floor.get("length") == args.length:
+                result["roofline"]["mixed_read_write_floor"] = {
+                    "ms": floor["floor_ms"], "tb_per_s": floor["floor_tb_per_s"], "frac_of_floor": floor["floor_ms"] / kernel_ms,
+                    "source": floor["source"], "note": "stored measurement of tools/hbm_mixed (its fastest form), not taken in this run"}
+        if traffic is not None:
+            result["roofline"]["traffic_pmc_round"] = pmc_entry("c2" if seq_only else "c3").get("round")
         if dist is not None:
             result["per_rank"] = {"kernel_ms": rank_ms, "parity_sample_ok": rank_ok,
                                   "note": "no 1 -> N curve is claimed by this line: value = all ranks' windows / max-over-ranks time"}
@@ -771,7 +786,11 @@ def main():
             big = ~vs & ~np.isnan(ref_st)
             big_ok = bool(np.array_equal(np.isnan(got_st), np.isnan(ref_st)) and
                           np.allclose(got_st[big], ref_st[big], rtol=1e-12, atol=0, equal_nan=True))
-            result["parity_on_sample"] = {"seq_f32_bit_exact": seq_ok, "struct_max_abs_err": st_err,
+            result["parity_on_sample"] = {"oracle_input": "same float32 profile (the synthetic stream is born float32: this measures the "
+                                                          "arithmetic, not what float32 STORAGE costs against float64 inputs -- that is "
+                                                          "bounded per PFM by scanner.float32_storage_bound and measured on the reference's "
+                                                          "example in tests/test_gpu_parity.py)",
+                                          "seq_f32_bit_exact": seq_ok, "struct_max_abs_err": st_err,
                                           "struct_within_1e-6": bool(st_err <= 1e-6 and big_ok)}
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
             if not args.no_ref_structured:

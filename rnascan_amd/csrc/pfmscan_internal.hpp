@@ -94,6 +94,8 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
 // pfmscan_letters8.hip: fp64 letter hits through the single-letter integer prefilter (false: not applicable, take the exact
 // kernel); fp64 letter score of a SECOND code stream at the candidates of a letters pass (two-FASTA combined scan)
 bool launch_letters_cred8(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err);
+// letters-only scans of PFMs wider than PFMSCAN_MAX_M: codes in LDS, the table streamed through LDS in 64-row slabs
+bool launch_wide_letters(const ScanArgs &a, hipStream_t stream, hipError_t *err);
 hipError_t launch_letters_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
                              const unsigned long long *cand_count, int cand_shards, int64_t cand_shard_cap,
                              hipStream_t stream);

@@ -51,6 +51,7 @@
 #include <float.h>
 #include <math.h>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "pfmscan_device.hpp"
@@ -1649,6 +1650,8 @@ __global__ __launch_bounds__(BLOCK) void k_wide(const ScanArgs a)
 static hipError_t launch_wide(const ScanArgs &a, hipStream_t stream)
 {
     if ((a.letter_table && !a.codes) || (a.struct_pssm && !a.profile)) return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    if (!std::getenv("PFMSCAN_WIDE_PLAIN") && launch_wide_letters(a, stream, &e)) return e;      // letters only: the slab kernel
     const unsigned grid = (unsigned)((a.n_pos + BLOCK - 1) / BLOCK);
     if (a.struct_pssm && a.profile_dtype == PFMSCAN_PROFILE_F64)
         hipLaunchKernelGGL(k_wide<double>, dim3(grid), dim3(BLOCK), 0, stream, a);

@@ -433,6 +433,126 @@ hipError_t launch_letters_at(const ScanArgs &a, const int64_t *cand_pos, const f
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// k_wide_letters -- letter tables WIDER than PFMSCAN_MAX_M (the reference's loops take any width: _pwm.c:34-68,
+// matrix.py:25-43).  k_letters' inner loop with the table streamed through LDS in slabs of 64 rows: a workgroup stages
+// the codes of its 2048 windows (+ m bytes of look-ahead) once, then for every slab loads 64 table rows (4 KB), each
+// thread reads the 72 code bytes its 8 consecutive windows meet in that slab as 18 aligned dwords and adds the rows
+// to its 8 running fp64 sums -- row after row, so the order of the additions, and with it every bit of the result, is
+// the reference's.  One guard per row (wave-uniform) ends the last slab.  Scores (float32 of the sum or the fp64 sum
+// itself) and hits (either compare) as in k_letters / k_wide.
+// ---------------------------------------------------------------------------
+constexpr int WIDE_SLAB = 64;
+constexpr int WIDE_W = 8;
+constexpr int WIDE_TILE = BLOCK * WIDE_W;
+static inline int wide_code_bytes(int m) { return WIDE_TILE + ((m + 15) & ~15) + 64; }
+
+template <typename OUT_T, bool HITS>
+__global__ __launch_bounds__(BLOCK) void k_wide_letters(const ScanArgs a)
+{
+    constexpr int W = WIDE_W;
+    extern __shared__ __align__(16) unsigned char wsmem[];
+    double *tbl = reinterpret_cast<double *>(wsmem);                      // [64][8]
+    uint8_t *cbuf = wsmem + WIDE_SLAB * 64;
+    const int m = a.m;
+    const int64_t n_pos = a.n_pos;
+    const int64_t tile0 = (int64_t)blockIdx.x * WIDE_TILE;
+    const int nvec = (WIDE_TILE + ((m + 15) & ~15) + 64) / 16;
+    for (int i = threadIdx.x; i < nvec; i += BLOCK) {
+        const int64_t p = tile0 + 16 * (int64_t)i;
+        u32x4 v = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
+        if (p + 16 <= n_pos) {
+            v = *reinterpret_cast<const u32x4 *>(a.codes + p);
+        } else if (p < n_pos) {
+            uint32_t t[4] = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
+            for (int b = 0; b < 16; ++b)
+                if (p + b < n_pos) t[b >> 2] = (t[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)a.codes[p + b] << (8 * (b & 3)));
+            v = u32x4{t[0], t[1], t[2], t[3]};
+        }
+        *reinterpret_cast<u32x4 *>(cbuf + 16 * i) = v;
+    }
+    double acc[W];
+#pragma unroll
+    for (int v = 0; v < W; ++v) acc[v] = 0.0;
+    for (int j0 = 0; j0 < m; j0 += WIDE_SLAB) {
+        __syncthreads();                               // the codes are staged / the previous slab is consumed
+        const int rows = m - j0 < WIDE_SLAB ? m - j0 : WIDE_SLAB;
+        for (int i = threadIdx.x; i < rows * 8; i += BLOCK) tbl[i] = a.letter_table[(size_t)j0 * 8 + i];
+        __syncthreads();
+        uint32_t w[18];
+#pragma unroll
+        for (int d = 0; d < 18; ++d)
+            w[d] = (*reinterpret_cast<const uint32_t *>(cbuf + threadIdx.x * W + j0 + 4 * d) & 0x07070707u) << 3;   // byte = code * sizeof(double)
+#pragma unroll
+        for (int j = 0; j < WIDE_SLAB; ++j) {
+            if (j < rows) {
+                const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+#pragma unroll
+                for (int v = 0; v < W; ++v) {
+                    const int q = j + v;
+                    const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+                    acc[v] += *reinterpret_cast<const double *>(row + b);
+                }
+            }
+        }
+    }
+    const int64_t p0 = tile0 + (int64_t)threadIdx.x * W;
+    if (HITS) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int v = 0; v < W; ++v) {
+            const double cmp = (sizeof(OUT_T) == 4 && !a.f64_hits) ? (double)(float)acc[v] : acc[v];
+            if (p0 + v < n_pos && cmp > a.thr_seq) mask |= 1u << v;
+        }
+        emit_hits_block<W>(mask, [&](int i) { return p0 + i; }, [&](int i) { return (float)acc[i]; }, [&](int i) { return acc[i]; }, a);
+        return;
+    }
+    if (sizeof(OUT_T) == 4) {
+        float *o = a.out_seq + p0;
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h) {
+            if (p0 + 4 * h + 4 <= n_pos) {
+                const f32x4 r = {(float)acc[4 * h], (float)acc[4 * h + 1], (float)acc[4 * h + 2], (float)acc[4 * h + 3]};
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(o + 4 * h));
+            } else {
+                for (int v = 0; v < 4; ++v)
+                    if (p0 + 4 * h + v < n_pos) o[4 * h + v] = (float)acc[4 * h + v];
+            }
+        }
+    } else {
+        double *o = a.out_letters_f64 + p0;
+#pragma unroll
+        for (int h = 0; h < W / 2; ++h) {
+            if (p0 + 2 * h + 2 <= n_pos) {
+                const f64x2 r = {acc[2 * h], acc[2 * h + 1]};
+                __builtin_nontemporal_store(r, reinterpret_cast<f64x2 *>(o + 2 * h));
+            } else if (p0 + 2 * h < n_pos) {
+                o[2 * h] = acc[2 * h];
+            }
+        }
+    }
+}
+
+// letters-only scans of a PFM wider than PFMSCAN_MAX_M (launch_wide in pfmscan_kernels.hip keeps the plain kernel for
+// scans with a structure part).  false: not this kernel's case.
+bool launch_wide_letters(const ScanArgs &a, hipStream_t stream, hipError_t *err)
+{
+    if (a.struct_pssm || !a.letter_table || !a.codes || a.m <= PFMSCAN_MAX_M) return false;
+    if (!a.hits && !a.out_seq && !a.out_letters_f64) return false;
+    const unsigned grid = (unsigned)((a.n_pos + WIDE_TILE - 1) / WIDE_TILE);
+    const int lds = WIDE_SLAB * 64 + wide_code_bytes(a.m);
+    if (a.hits) {
+        if (a.f64_hits) hipLaunchKernelGGL((k_wide_letters<double, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
+        else hipLaunchKernelGGL((k_wide_letters<float, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    } else if (a.out_letters_f64) {
+        hipLaunchKernelGGL((k_wide_letters<double, false>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((k_wide_letters<float, false>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    }
+    *err = hipGetLastError();
+    return true;
+}
+
 }  // namespace pfmscan
 
 // Diagnostics (host only): the single-letter credit table k_letters_cred8 would use for one motif at threshold thr

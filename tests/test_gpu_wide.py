@@ -1,6 +1,6 @@
 """PFMs wider than PFMSCAN_MAX_M = 64 (the reference's loops take any width: _pwm.c:34-68, matrix.py:25-43,
-rnascan.py:302-307).  They run the plain one-thread-per-window kernel (k_wide); every mode of the C ABI gives what the CPU
-oracle gives: float32 sequence scores bit for bit, structure scores within 1e-6, the same hit positions."""
+rnascan.py:302-307).  Letters-only scans run the slab kernel (k_wide_letters), scans with a structure part the plain
+one-thread-per-window kernel (k_wide); every mode of the C ABI gives what the CPU oracle gives: float32 sequence scores bit for bit, structure scores within 1e-6, the same hit positions."""
 import io
 
 import numpy as np
@@ -100,3 +100,35 @@ def test_wide_pfm_through_the_command_line(tmp_path):
     eng.close()
     assert want.getvalue().count("\n") > 100
     assert got.getvalue() == want.getvalue()
+
+
+@pytest.mark.parametrize("m", [65, 128, 129, 640, 1500, 4096])
+def test_wide_letters_slab_kernel_over_many_tiles(ctx, oracle, m, monkeypatch):
+    """the slab kernel of letters-only wide PFMs (k_wide_letters: codes in LDS, the table through LDS 64 rows at a time) on a
+    stream of many tiles, slab counts with and without a ragged last slab: float32 scores bit for bit, fp64 scores exactly
+    (same order of additions), the same hits -- and the same as the plain one-thread-per-window kernel (PFMSCAN_WIDE_PLAIN)"""
+    rng = np.random.default_rng(13 * m)
+    s = rand_stream(rng, 7, m, 3 * m + 5000, foreign=0.0002)
+    T = rand_table(rng, m)
+    motif = ctx.motif(T, None)
+    want32, want64 = oracle.stream_seq(s.codes, T), oracle.stream_letters_f64(s.codes, T)
+    ctx.stage(s.codes, None)
+    got32, _ = ctx.scan_staged(motif)
+    assert_f32_bits_equal(got32, want32)
+    got64 = ctx.scan_letters_f64_host(motif, s.codes)
+    ok = ~np.isnan(want64)
+    assert np.array_equal(np.isnan(got64), ~ok) and np.array_equal(got64[ok], want64[ok])
+    fin = want32[np.isfinite(want32)].astype(np.float64)
+    thr = _clear_of(fin, _below_max(fin, 0.7))
+    pos, hs, _ = ctx.hits_host(motif, s.codes, None, thr, -np.inf)
+    wpos = oracle.stream_hits(want32, None, thr, -np.inf)
+    assert len(wpos) > 5 and np.array_equal(pos, wpos)
+    assert_f32_bits_equal(hs, want32[wpos])
+    pos64, sc64 = ctx.hits_letters_f64_host(motif, s.codes, thr)
+    w64 = oracle.stream_hits(None, want64, -np.inf, thr)
+    assert np.array_equal(pos64, w64) and np.array_equal(sc64, want64[w64])
+    monkeypatch.setenv("PFMSCAN_WIDE_PLAIN", "1")
+    ctx.stage(s.codes, None)
+    plain32, _ = ctx.scan_staged(motif)
+    assert_f32_bits_equal(plain32, got32)
+    motif.close()
