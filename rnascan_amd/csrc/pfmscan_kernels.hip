@@ -4,7 +4,7 @@
 // is HBM streaming: every input byte is read once with 16-byte-per-lane
 // coalesced accesses, every output byte written once with 16-byte-per-lane stores.
 //
-// Kernels (DESIGN.md section 5 has the measurements behind each choice):
+// Kernels (the measurements behind each choice: profiles/r3/NOTES.md, profiles/r4/NOTES.md):
 //
 //  k_letters   codes only (config 2 and the letter-string structure scan).  A workgroup
 //              parks its tile's codes in LDS once (16-byte vector loads); a thread owns
@@ -1550,7 +1550,7 @@ static hipError_t launch_letters_ndw(const ScanArgs &a, const Tuning &t, hipStre
 static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t stream)
 {
     hipError_t e = hipSuccess;
-    if (launch_letters_quad(a, t, stream, &e)) return e;     // PFMSCAN_QUAD=1 only: measured slower ("tried")
+    if (launch_letters_quad(a, t, stream, &e)) return e;     // PFMSCAN_QUAD=1 only: measured slower (profiles/r3/NOTES.md, "tried and dropped")
     if (launch_letters_cred(a, t, stream, &e)) return e;
     if (launch_letters_cred8(a, t, stream, &e)) return e;    // fp64 hits of a generic alphabet at a finite threshold
     if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
