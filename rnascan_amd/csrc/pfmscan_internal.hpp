@@ -180,6 +180,7 @@ struct LibArgs {
     const double *pssm;                   // [m * 4][nmp][2] fp64: row j, column pair c/2, motif, c&1 (column 7 = 0); null = no structure side
     const double *thr_seq, *thr_struct;   // [nmp]
     int m, npair, nmp, ng, motif_base;
+    int sort_batches;                     // A/B: phase B sorts each 64-item batch by motif group (PFMSCAN_LIB_SORT=1)
     int ng_real;                          // motif groups of the pass that hold motifs (<= ng, the layout of its tables): the rest is skipped
     // Teams: passes SIDE BY SIDE in one launch.  Workgroups [team_first[t], team_first[t + 1]) run pass t of n_teams
     // consecutive passes whose tables lie stride_* elements apart (same ng layout) and whose motifs start nmp apart;

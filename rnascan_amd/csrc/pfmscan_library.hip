@@ -371,8 +371,35 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const bool have = lane < cnt;
         const int idx = first + (have ? lane : 0);
-        const uint32_t rel = q_pos[idx];
-        const uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
+        uint32_t rel = q_pos[idx];
+        uint32_t p0 = q_p0[idx], p1 = q_p1[idx];
+        if (MPG == 12 && a.sort_batches) {
+            // A/B (PFMSCAN_LIB_SORT=1): the batch in the order of the motif GROUP each item works on -- a counting sort by
+            // ballots.  The 12 motifs of a group are 12 consecutive 16-byte PSSM cells = 12 distinct bank groups, so lanes
+            // of one group read their cells without conflicts (unsorted: 96 motifs at random, ~2.7-way).
+            const uint32_t key = have ? (uint32_t)__builtin_ctz((p0 & 0xFFFFu) | 0x10000u) : 31u;
+            int rank = 0, base = 0;
+#pragma unroll
+            for (int v = 0; v < NG; ++v) {
+                const unsigned long long mv = __builtin_amdgcn_ballot_w64(key == (uint32_t)v);
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+                rank = key == (uint32_t)v ? base + below : rank;
+                base += __popcll(mv);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();               // every lane has read its item
+            if (have) {
+                q_pos[first + rank] = rel;
+                q_p0[first + rank] = p0;
+                q_p1[first + rank] = p1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            rel = q_pos[idx];
+            p0 = q_p0[idx];
+            p1 = q_p1[idx];
+        }
         // An item of the twelve-per-entry form: p0 = the mask of flagged groups (bits 0-15), p1 = the window's letters.  The
         // batch works on the LOWEST flagged group g: its credit sums are looked up once more (npair look-ups for 64 items at
         // once) to see which of its motifs were flagged -- bit 4 f + d of `bits` = motif 3 d + f.  An item that came back

@@ -436,6 +436,10 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
             LibArgs a;
             std::memset(&a, 0, sizeof(a));
             a.ng_real = ps.ng_real;
+            {
+                static const int sort_env = std::getenv("PFMSCAN_LIB_SORT") ? std::atoi(std::getenv("PFMSCAN_LIB_SORT")) : 0;
+                a.sort_batches = sort_env;
+            }
             if (nt > 1) {
                 // shares of the grid ~ the cost of a pass: measured 0.385 ms per motif group + 0.66 ms on C5 with float32 rows
                 // (flat around it: 0 .. 1.5 for the constant give the same time within the noise); with float64 rows the

@@ -388,3 +388,83 @@ def test_fullsize_c4_shard_of_125k_records(oracle):
         assert np.abs(got_st - ref_st[: L - M + 1]).max() <= 1e-6
     motif.close()
     ctx.close()
+
+
+def test_fullsize_structure_letter_strings_and_two_fasta(big, oracle):
+    """SURVEY 8f N4 at full size (100k x 3 kb structure strings, 7 letters, w = 12): the fp64 letter hits are exactly the
+    windows the all-scores output (k_letters<..., double>) says exceed the threshold, with the same bits; doubling the
+    table doubles every hit's score exactly and keeps the hit set at the doubled threshold; the two-stream hits are the
+    intersection of the two single-stream hit sets (combine()'s inner join, rnascan.py:416-434); 32 records picked at random
+    match the CPU oracle."""
+    torch = big["torch"]
+    from rnascan_amd import _lib
+    ctx, dev, n_pos = big["ctx"], big["dev"], big["n_pos"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    scodes = torch.randint(0, 7, (R, L + 1), dtype=torch.uint8, device=dev, generator=g)
+    scodes |= (torch.rand((R, L + 1), device=dev, generator=g) < 0.25).to(torch.uint8) * 8        # letters written in lower case
+    scodes[torch.rand((R, L + 1), device=dev, generator=g) < 0.0005] = 7                           # foreign letters
+    scodes[:, L] = 7
+    scodes = scodes.view(-1)
+    rng = np.random.default_rng(5)
+    T = np.full((M, 8), np.nan)
+    T[:, :7] = rng.normal(-0.6, 1.8, size=(M, 7))
+    T[rng.integers(0, M), rng.integers(0, 7)] = -np.inf
+    mo = ctx.motif(T, None)
+    full = torch.empty(n_pos, dtype=torch.float64, device=dev)
+    ctx.scan_letters_f64_dev(mo, scodes.data_ptr(), n_pos, full.data_ptr())
+    ctx.synchronize()
+    fin = full[torch.isfinite(full)]
+    thr = float(torch.quantile(fin[:4_000_000], 0.9995)) + 1e-7
+    cap = 1 << 22
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    ht = torch.empty(cap, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def letter_hits(motif, threshold):
+        cnt.zero_()
+        torch.cuda.synchronize()
+        ctx.hits_letters_f64_dev(motif, scodes.data_ptr(), n_pos, threshold, cap, hp.data_ptr(), ht.data_ptr(), cnt.data_ptr())
+        ctx.synchronize()
+        k = int(cnt.item())
+        assert 0 < k <= cap
+        order = torch.argsort(hp[:k])
+        return hp[:k][order].clone(), ht[:k][order].clone()
+
+    pos, sc = letter_hits(mo, thr)
+    want = torch.nonzero(full > thr).flatten()
+    assert torch.equal(pos, want) and torch.equal(sc.view(torch.int64), full[want].view(torch.int64))
+    assert 50_000 < pos.numel() < 400_000
+    mo2 = ctx.motif(2.0 * T, None)
+    pos2, sc2 = letter_hits(mo2, 2.0 * thr)
+    assert torch.equal(pos2, pos) and torch.equal(sc2, 2.0 * sc)
+    mo2.close()
+    # two code streams: sequence PFM (float32 compare) AND structure letters (fp64 compare)
+    mq = ctx.motif(big["table"], None)
+    sq = torch.empty(n_pos, dtype=torch.float32, device=dev)
+    ctx.scan_dev(mq, big["codes"].data_ptr(), None, _lib.PROFILE_NONE, n_pos, sq.data_ptr(), None)
+    ctx.synchronize()
+    thr_q, thr_t = 4.0, float(torch.quantile(fin[:4_000_000], 0.9)) + 1e-7
+    cnt.zero_()
+    torch.cuda.synchronize()
+    ctx.hits_pair_dev(mq, mo, big["codes"].data_ptr(), scodes.data_ptr(), n_pos, thr_q, thr_t, cap, hp.data_ptr(), hs.data_ptr(),
+                      ht.data_ptr(), cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    order = torch.argsort(hp[:k])
+    want = torch.nonzero((sq.double() > thr_q) & (full > thr_t)).flatten()
+    assert k == want.numel() and k > 1000 and torch.equal(hp[:k][order], want)
+    assert torch.equal(hs[:k][order].view(torch.int32), sq[want].view(torch.int32))
+    assert torch.equal(ht[:k][order].view(torch.int64), full[want].view(torch.int64))
+    # sampled records against the CPU oracle
+    stride = L + 1
+    for r in rng.integers(0, R, size=32).tolist():
+        rec = scodes[r * stride:(r + 1) * stride].cpu().numpy()
+        w = oracle.stream_letters_f64(rec, T)
+        gq = full[r * stride:(r + 1) * stride].cpu().numpy()
+        ok = ~np.isnan(w)
+        assert np.array_equal(np.isnan(gq), ~ok) and np.array_equal(gq[ok], w[ok])
+    mo.close()
+    mq.close()
