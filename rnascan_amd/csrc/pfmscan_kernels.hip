@@ -432,12 +432,15 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     constexpr int LET_TILE = BLOCK * W;
     constexpr int NPOS = W + 4 * NJ - 2;               // positions a lane looks up: q = 0 .. W + 4 NJ - 3
     constexpr int NWD = (NPOS + 1 + 3) / 4;            // code dwords holding bytes 0 .. NPOS (the pair at q needs byte q + 1)
-    constexpr int ESH = NJ == 1 ? 2 : (NJ == 2 ? 3 : (NJ <= 4 ? 4 : 5));   // log2 of the entry size in bytes
+    // entry STRIDE in bytes: 4 / 8 / 16 for up to 4 row pairs (16 entries span at most 256 B = every bank once); 5..8 row pairs
+    // need 32 bytes, 16 of them = the banks TWICE (entries e and e + 8 collide 2-way) -- stride 48 spreads the 16-byte pieces
+    // of the 16 entries over 16 different bank quads again (12 e mod 64 is a permutation of the multiples of 4)
+    constexpr int ESTR = NJ == 1 ? 4 : (NJ == 2 ? 8 : (NJ <= 4 ? 16 : 48));
     constexpr int TROWS = NJ <= 4 ? 16 : 32;           // rows of the exact letter table (rows m .. are zeros)
     constexpr int NWAVE = BLOCK / 64;
     typedef typename CredEntry<NJ>::type entry_t;
     __shared__ __align__(16) double tbl[TROWS * 8];
-    __shared__ __align__(16) uint32_t ctab[16 << (ESH - 2)];
+    __shared__ __align__(16) uint32_t ctab[16 * (ESTR / 4)];
     __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
     __shared__ uint32_t q_pos[NWAVE][WQ_CAP];          // positions in both queues are relative to the workgroup's first tile:
     __shared__ float q_sc[NWAVE][WQ_CAP];
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     cs.fetch(a.codes, first, n_pos);
     // rows m .. are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
     for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
-    for (int i = threadIdx.x; i < (16 << (ESH - 2)); i += BLOCK) ctab[i] = ct.d[i >> (ESH - 2)][i & ((1 << (ESH - 2)) - 1)];
+    for (int i = threadIdx.x; i < 16 * (ESTR / 4); i += BLOCK) ctab[i] = (i % (ESTR / 4)) < 8 ? ct.d[i / (ESTR / 4)][i % (ESTR / 4)] : 0u;
     if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
     cs.park(cbuf[0]);
     if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
@@ -542,13 +545,13 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         const uint8_t *cb = cbuf[tb & 1];
         const int off0 = threadIdx.x * W;
         // xm[d] = the low two bits of the four codes at bytes 4d .. 4d+3.  The entry offset of the pair at byte q,
-        // (c[q] | c[q+1] << 2) << ESH, is ONE v_dot4_u32_u8 of that dword with the weights (1, 4) << ESH placed on
+        // (c[q] | c[q+1] << 2) x ESTR, is ONE v_dot4_u32_u8 of that dword with the weights (1, 4) x ESTR placed on
         // bytes q & 3 and (q & 3) + 1 -- plus a v_alignbyte when the pair straddles two dwords.  (Shift / or / mask per
         // dword and a byte extraction + shift per position were a third of the kernel's VALU instructions.)
         uint32_t xm[NWD + 1];
 #pragma unroll
         for (int d = 0; d < NWD + 1; ++d) xm[d] = *reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d) & 0x03030303u;   // inside the halo
-        constexpr uint32_t WT = (1u << ESH) | (4u << ESH) << 8;       // weights of a pair's two letters
+        constexpr uint32_t WT = (uint32_t)ESTR | (uint32_t)(4 * ESTR) << 8;       // weights of a pair's two letters (4 x 48 = 192 fits a byte)
         // one look-up per position; P[w + 2] in the text above is pk[w + 2] here (w = -2 .. W-1)
         uint32_t pk[W + 2];
 #pragma unroll

@@ -49,9 +49,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
     constexpr int LET_TILE = BLOCK * W;
     constexpr int NPOS = W + 2 * NJ - 1;               // positions a lane looks up: q = 0 .. W + 2 NJ - 2
     constexpr int NWD = (NPOS + 3) / 4;                // code dwords holding bytes 0 .. NPOS - 1
-    constexpr int ESH = NJ <= 2 ? 3 : (NJ <= 4 ? 4 : (NJ <= 8 ? 5 : 6));   // log2 of the entry size in bytes
-    constexpr int PSH = ESH < 5 ? ESH : 5;             // the codes are pre-shifted inside their bytes (7 << 5 still fits)
-    constexpr int EDW = 1 << (ESH - 2);                // dwords per entry
+    // entry STRIDE in bytes: 8 / 16 / 32 for up to 8 row pairs (8 entries span at most 256 B = every bank once); wider entries
+    // would be 64 bytes, 8 of them = the banks TWICE (codes c and c + 4 on the same banks: 2-way conflicts, measured +50 % at
+    // w = 18 against w = 16) -- stride 80 puts the 16-byte pieces of the 8 codes on 8 different bank quads again
+    constexpr int ESTR = NJ <= 2 ? 8 : (NJ <= 4 ? 16 : (NJ <= 8 ? 32 : 80));
+    constexpr int PSH = NJ <= 2 ? 3 : 4;               // the codes are pre-shifted inside their bytes: byte = code * 8 or code * 16
+    constexpr int EDW = ESTR / 4;                      // dwords per entry
     constexpr int TROWS = 2 * NJ;                      // rows of the exact letter table (rows m .. are zeros)
     constexpr int NRAW = (2 * NJ + 3) / 4 + 1;         // aligned code dwords that hold a window's 2 NJ letters at any p & 3
     constexpr int NWAVE = BLOCK / 64;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
     for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
     // the credit table comes from device memory (a.d_cred8, [8][16] dwords): as a by-value kernel argument its per-lane
     // indexing kept all 128 dwords in SGPRs and the widest instantiation spilled 57 of them to VGPR lanes
-    for (int i = threadIdx.x; i < 8 * EDW; i += BLOCK) ctab[i] = (i & (EDW - 1)) < NJ ? a.d_cred8[(i >> (ESH - 2)) * 16 + (i & (EDW - 1))] : 0u;
+    for (int i = threadIdx.x; i < 8 * EDW; i += BLOCK) ctab[i] = (i % EDW) < NJ ? a.d_cred8[(i / EDW) * 16 + (i % EDW)] : 0u;
     if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
     cs.park(cbuf[0]);
     if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
         if (tile0 >= n_pos) break;                     // uniform; the previous tile flushed (it was the last)
         const uint8_t *cb = cbuf[tb & 1];
         const int off0 = threadIdx.x * W;
-        // xs[d] byte k = (code at byte 4d + k) << PSH: the entry offset of position q is one v_bfe_u32 (and a shift by one
+        // xs[d] byte k = (code at byte 4d + k) << PSH: the entry offset of position q is one v_bfe_u32 (and one more
         // for 64-byte entries)
         uint32_t xs[NWD];
 #pragma unroll
@@ -172,7 +175,18 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
         for (int i = 0; i < W + 1; ++i) pk[i] = 0u;
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
-            const uint32_t off = ((xs[q >> 2] >> (8 * (q & 3))) & 0xFFu) << (ESH - PSH);
+            // ONE v_bfe_u32 per position, written out: hipcc knows that only bits 5-7 of a byte can be set, narrows the
+            // mask to 0xE0 and then no longer recognises the bit-field extract -- it issued a shift AND a mask per position,
+            // 2 of the body's 9 VALU instructions per window
+            uint32_t off;
+            switch (q & 3) {                            // q is an unrolled loop index: the switch folds
+            case 0: asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
+            case 1: asm("v_bfe_u32 %0, %1, 8, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
+            case 2: asm("v_bfe_u32 %0, %1, 16, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
+            default: asm("v_bfe_u32 %0, %1, 24, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
+            }
+            if constexpr (ESTR == 32) off <<= 1;       // byte = code * 16
+            if constexpr (ESTR == 80) off += off << 2;  // code * 16 * 5: one v_lshl_add_u32
             // position q feeds the windows u = q - 2k in [0, W], i.e. the row pairs k in [(q - W + 1) / 2, q / 2]: at most
             // W / 2 + 1 of the NJ dwords of its entry -- only the 16-byte groups that hold one of them are read
             constexpr int KMAX = NJ - 1;
@@ -352,6 +366,7 @@ bool launch_letters_cred8(const ScanArgs &a, const Tuning &t, hipStream_t stream
     else if (nj <= 4) hipLaunchKernelGGL((k_letters_cred8<4>), dim3(g), dim3(BLOCK), 0, stream, b);
     else if (nj <= 6) hipLaunchKernelGGL((k_letters_cred8<6>), dim3(g), dim3(BLOCK), 0, stream, b);
     else if (nj <= 8) hipLaunchKernelGGL((k_letters_cred8<8>), dim3(g), dim3(BLOCK), 0, stream, b);
+    else if (nj <= 10) hipLaunchKernelGGL((k_letters_cred8<10>), dim3(g), dim3(BLOCK), 0, stream, b);     // the reference's example PFMs are 18 wide
     else if (nj <= 12) hipLaunchKernelGGL((k_letters_cred8<12>), dim3(g), dim3(BLOCK), 0, stream, b);
     else hipLaunchKernelGGL((k_letters_cred8<16>), dim3(g), dim3(BLOCK), 0, stream, b);
     *err = hipGetLastError();

@@ -67,7 +67,7 @@ def test_hits_letters_f64_every_width(ctx, oracle, m):
     mo.close()
 
 
-@pytest.mark.parametrize("nj", [4, 8, 12, 16])
+@pytest.mark.parametrize("nj", [4, 8, 10, 12, 16])
 def test_hits_letters_f64_every_bucket_of_the_prefilter(ctx, oracle, nj, monkeypatch):
     """every instantiation of k_letters_cred8 on PFMs narrower than it is sized for (rows beyond the width carry no
     credit).  The widest one once came out of the compiler wrong when it was free to use more than 128 VGPRs; it is built
