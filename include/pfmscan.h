@@ -392,6 +392,10 @@ int pfmscan_upload_source_file_checked(pfmscan_ctx *ctx, const void *base, size_
  * pfmscan_fasta_encode: records [lo, hi) -> codes[sum(n_letters + 1)]: lut256[byte] per letter, `separator`
  *   after each record (stream layout above); offsets[i] = stream position of record lo + i.  n_threads <= 0:
  *   as many as the host offers, at most 16. */
+/* pfmscan_count_bytes: counts[256] = how often each byte value occurs in buf (parallel).  Over a packed code stream this
+ * is compute_background's letter count (rnascan/rnascan.py:444-457: Seq.count per letter over every record) in one pass:
+ * codes 0..6 are the alphabet's letters as written in upper case, 8..14 the lower-case ones, 7 separators / foreign. */
+int pfmscan_count_bytes(const uint8_t *buf, int64_t n, int64_t *counts /* [256] */, int n_threads);
 /* pfmscan_fasta_lone_cr: *found = 1 when buf holds a carriage return that is not followed by a line feed (old-Mac line
  * ends: the reference's universal-newline reader breaks lines there, pfmscan_fasta_index at \n only -- the caller
  * parses such a file the slow way).  One parallel pass at memory speed over the WHOLE buffer. */

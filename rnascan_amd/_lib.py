@@ -37,7 +37,7 @@ SYMBOLS = [
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
     "pfmscan_hits_pair_dev", "pfmscan_stage_codes2", "pfmscan_hits_pair_staged", "pfmscan_hits_pair_host", "pfmscan_round_decimals",
-    "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_upload_source_file_checked", "pfmscan_fasta_lone_cr", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
+    "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_upload_source_file_checked", "pfmscan_fasta_lone_cr", "pfmscan_count_bytes", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -132,6 +132,7 @@ def load():
     L.pfmscan_upload_source_file.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64]
     L.pfmscan_upload_source_file_checked.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64, i64, i64, i64]
     L.pfmscan_fasta_lone_cr.argtypes = [vp, i64, ctypes.POINTER(i32), i32]
+    L.pfmscan_count_bytes.argtypes = [vp, i64, vp, i32]
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
@@ -226,6 +227,17 @@ def fasta_lone_cr(buf, threads=0):
     if rc != OK:
         _raise(L, None, rc)
     return bool(found.value)
+
+
+def count_bytes(buf, threads=0):
+    """int64 [256]: occurrences of every byte value in a uint8 array (numpy.bincount widens 3x10^8 bytes to int64 first: 10 s)"""
+    L = load()
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    counts = np.zeros(256, dtype=np.int64)
+    rc = L.pfmscan_count_bytes(_ptr(buf), buf.size, _ptr(counts), int(threads))
+    if rc != OK:
+        _raise(L, None, rc)
+    return counts
 
 
 def fasta_ids(buf, hdr_off, hdr_len):

@@ -143,7 +143,7 @@ def _same_records(seq_fasta, struct_fasta):
     order, every id once -- the shape `rnascan seqs.fa structs.fa` is made for: record k of one file pairs with record k
     of the other and a batch of the join is the join of a batch.  Otherwise None: the two tables are made and joined as the
     reference does (rnascan.py:416-434)."""
-    recs, srecs = fasta.LazyFasta(seq_fasta), fasta.LazyFasta(struct_fasta)
+    recs, srecs = fasta.open_lazy(seq_fasta), fasta.open_lazy(struct_fasta)
     ids = list(recs.ids)
     ok = len(recs) == len(srecs) and len(recs) > 0 and ids == list(srecs.ids) and len(set(ids)) == len(ids)
     return (recs, srecs) if ok else None
@@ -226,7 +226,7 @@ def scan_main(engine, source, pssm, letters, args, dist_ctx=(0, 1, None), sink=N
         fasta.eprint("Processed %d sequences" % len(files))
         return df
     fasta.eprint("Scanning sequences ")
-    recs = fasta.LazyFasta(source)                     # index only: a rank / a batch reads just its own records
+    recs = fasta.open_lazy(source)                     # index only: a rank / a batch reads just its own records
     # nucleotide letters only: a position is one byte on the device and four in the score array, so a launch takes 8 x the
     # positions a profile batch may hold
     df = shard.scan_sharded(recs, recs.lengths,
@@ -356,7 +356,7 @@ def main(argv=None, engine=None, out=None):
         # Only an index of both sides is held; a batch reads its own records and the profiles of those records.
         ptype = profile_type(args, struct_pssm)
         fasta.eprint("Scanning sequences ")
-        recs = fasta.LazyFasta(seq_source)
+        recs = fasta.open_lazy(seq_source)
         fasta.eprint("Processed %d sequences" % len(recs))
         fasta.eprint("Scanning averaged secondary structures ")
         ps = None

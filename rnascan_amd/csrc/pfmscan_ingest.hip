@@ -214,6 +214,32 @@ void index_piece(const uint8_t *buf, int64_t n, int64_t from, int64_t to, bool c
 
 extern "C" {
 
+int pfmscan_count_bytes(const uint8_t *buf, int64_t n, int64_t *counts, int n_threads)
+{
+    if ((!buf && n > 0) || n < 0 || !counts) return fail(nullptr, PFMSCAN_E_BADARG, "count_bytes: bad argument");
+    const int threads = pick_threads(n_threads, n >> 20);
+    std::vector<int64_t> part((size_t)threads * 256, 0);
+    parallel_ranges(n, threads, [&](int t, int64_t a, int64_t b) {
+        // four interleaved histograms: neighbouring equal bytes (homopolymers, separators) would otherwise serialise on one counter
+        int64_t h[4][256] = {};
+        int64_t i = a;
+        for (; i + 4 <= b; i += 4) {
+            ++h[0][buf[i]];
+            ++h[1][buf[i + 1]];
+            ++h[2][buf[i + 2]];
+            ++h[3][buf[i + 3]];
+        }
+        for (; i < b; ++i) ++h[0][buf[i]];
+        for (int v = 0; v < 256; ++v) part[(size_t)t * 256 + v] = h[0][v] + h[1][v] + h[2][v] + h[3][v];
+    });
+    for (int v = 0; v < 256; ++v) {
+        int64_t sum = 0;
+        for (int t = 0; t < threads; ++t) sum += part[(size_t)t * 256 + v];
+        counts[v] = sum;
+    }
+    return PFMSCAN_OK;
+}
+
 int pfmscan_fasta_lone_cr(const uint8_t *buf, int64_t n, int *found, int n_threads)
 {
     if ((!buf && n > 0) || n < 0 || !found) return fail(nullptr, PFMSCAN_E_BADARG, "fasta_lone_cr: bad argument");

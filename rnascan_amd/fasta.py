@@ -335,6 +335,27 @@ class LazyFasta(object):
                 yield rec
 
 
+_LAZY_CACHE = {}
+
+
+def open_lazy(fasta_files):
+    """LazyFasta(fasta_files), indexed once per process: the background pass (rnascan.py:440-465) and the scan
+    (rnascan.py:379) walk the same files.  Keyed by path, size and mtime of every file; the two most recent are kept (the
+    sequence and the structure FASTA of a two-file run)."""
+    files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
+    try:
+        key = tuple((f, os.path.getsize(f), os.stat(f).st_mtime_ns) for f in files)
+    except OSError:
+        return LazyFasta(files)
+    got = _LAZY_CACHE.pop(key, None)
+    if got is None:
+        got = LazyFasta(files)
+        while len(_LAZY_CACHE) >= 2:
+            _LAZY_CACHE.pop(next(iter(_LAZY_CACHE)))
+    _LAZY_CACHE[key] = got                               # most recently used last
+    return got
+
+
 def _record(header, chunks):
     words = header.split(None, 1)
     rid = words[0] if words else ""
@@ -356,15 +377,15 @@ def _count_letters_natively(fasta_files, lut, positions=1 << 26):
     files = [fasta_files] if isinstance(fasta_files, str) else list(fasta_files)
     if any(os.path.splitext(f)[1] in (".gz", ".bz2") for f in files):
         return None
-    from . import shard
-    lazy = LazyFasta(files)
+    from . import _lib, shard
+    lazy = open_lazy(files)
     counts = np.zeros(256, dtype=np.int64)
     for lo, hi in shard.batches(lazy.lengths, 0, len(lazy), positions):
         if hi > lo:
             packed = lazy[lo:hi].pack_letters(lut)
             if packed is None:
                 return None
-            counts += np.bincount(packed[0], minlength=256)
+            counts += _lib.count_bytes(packed[0])
     return counts[:8]
 
 

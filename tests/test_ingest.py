@@ -423,3 +423,28 @@ def test_staged_upload_source_must_still_be_the_mapped_file(tmp_path):
     buf = np.zeros(4096, dtype=np.uint8)
     rc = L.pfmscan_upload_source_file_checked(None, buf.ctypes.data_as(ctypes.c_void_p), 4096, os.fsencode(str(p)), 0, st.st_dev, st.st_ino, st.st_size)
     assert rc == _lib.E_BADARG                     # no context: refused before the file is looked at
+
+
+def test_count_bytes_and_background_of_a_structure_fasta(tmp_path):
+    """compute_background (rnascan.py:440-465) over a structure FASTA: counted from the packed codes by the native byte
+    histogram -- upper-case letters only, as Seq.count does on the untouched record (rnascan.py:186-197) -- and equal to
+    the parsed-record path"""
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, size=1_000_003).astype(np.uint8)
+    assert np.array_equal(_lib.count_bytes(x), np.bincount(x, minlength=256)) and _lib.count_bytes(x[:0]).sum() == 0
+    p = tmp_path / "t.fa"
+    with open(p, "w") as f:
+        for i in range(50):
+            f.write(">r%d\n%s\n" % (i, "".join(rng.choice(list("EHTBLRMehtblrmX"), size=int(rng.integers(0, 300))))))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        native = fasta.compute_background(str(p), fasta.STRUCT, verbose=False)
+        gz = tmp_path / "t.fa.gz"
+        import gzip
+        gz.write_bytes(gzip.compress(p.read_bytes()))
+        parsed = fasta.compute_background(str(gz), fasta.STRUCT, verbose=False)        # compressed: the parsed-record path
+    assert native == parsed and abs(sum(native.values()) - 1.0) < 1e-12
+    assert fasta.open_lazy(str(p)) is fasta.open_lazy(str(p))                          # indexed once
+    p.write_text(">only\nEEE\n")
+    assert len(fasta.open_lazy(str(p))) == 1                                           # a changed file is indexed again
