@@ -58,8 +58,9 @@ extern "C" {
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
 #define PFMSCAN_MAX_M   64     /* widest PFM of the tuned kernels and of PFM libraries (pfmscan_library_create) */
 #define PFMSCAN_MAX_WIDTH 4096 /* widest PFM accepted by pfmscan_motif_create / pfmscan_pwm_calculate: the reference's loops take
-                                  any width (_pwm.c:34-68, rnascan.py:302-307); widths above PFMSCAN_MAX_M run a plain
-                                  one-thread-per-window kernel with rolled loops -- same results, no speed claim */
+                                  any width (_pwm.c:34-68, rnascan.py:302-307).  Above PFMSCAN_MAX_M: letters-only scans run a
+                                  slab-tiled kernel (the table through LDS 64 rows at a time), scans with a structure part the
+                                  profile kernel up to 180 rows and a plain one-thread-per-window kernel beyond -- same results */
 
 #define PFMSCAN_OK          0
 #define PFMSCAN_E_BADARG   -1  /* NULL / negative / inconsistent argument   -> ValueError */

@@ -1667,7 +1667,13 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
 {
     *what = "launch";
     if (a.n_pos <= 0) return hipSuccess;
-    if (a.m > PFMSCAN_MAX_M) return launch_wide(a, stream);
+    // PFMs wider than PFMSCAN_MAX_M: letters only -> the slab kernel (launch_wide); with a structure part k_profile itself
+    // takes widths up to PROFILE_MAX_M (its loops are generic in m; the bound is the output staging of emit_tile_wave, which
+    // lives in the part of a wave's band that the NEXT wave does not read: m - 1 + 64 V 12 / 28 rows < 64 V), beyond that
+    // the plain one-thread-per-window kernel
+    constexpr int PROFILE_MAX_M = 180;
+    const bool profile_ok = a.struct_pssm && a.profile && !a.out_letters_f64 && a.m <= PROFILE_MAX_M && !std::getenv("PFMSCAN_WIDE_PLAIN");
+    if (a.m > PFMSCAN_MAX_M && !profile_ok) return launch_wide(a, stream);
     if (!a.struct_pssm) return launch_letters(a, t, stream);
     if (a.out_letters_f64 || a.profile == nullptr) return hipErrorInvalidValue;
     const bool has_seq = a.letter_table != nullptr;

@@ -12,7 +12,7 @@ from test_gpu_parity import rand_stream, rand_struct_pssm, rand_table
 
 pytestmark = pytest.mark.gpu
 
-WIDTHS = [65, 100, 257]
+WIDTHS = [65, 100, 180, 181, 257]      # up to 180 a structure part runs k_profile itself, beyond it the plain k_wide
 
 
 @pytest.mark.parametrize("m", WIDTHS)
