@@ -293,7 +293,8 @@ def secondary_legs(torch, _lib, ctx, args, dev, codes, profile, ptype, n_pos, ou
                           ht.data_ptr(), cnt.data_ptr(), stream)
     ms = timed(torch, pair, 10, 2)
     out["rnass_two_fasta"] = {"workload": "two-FASTA RNASS: sequence PFM (w=12) AND structure letter-string PFM (w=12) at -m 6 over the "
-                                          "two code streams: letters pass + k_letters_at at its hits (incl. the count read-back)",
+                                          "two code streams in ONE launch: k_letters_cred<.., PAIR> verifies the structure letters of its "
+                                          "own survivors",
                               "ms_per_step": ms, "steps": 10, "value": w12 / (ms * 1e-3), "unit": "windows/s",
                               "hits_per_step": int(cnt.item()), "minscore": 6.0}
     ms7.close()

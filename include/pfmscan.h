@@ -246,8 +246,10 @@ int pfmscan_hits_letters_f64_host(pfmscan_ctx *ctx, const pfmscan_motif *motif,
  * (float32 of the fp64 sum, _pwm.c:34-68), codes2 = the structure letters of the SAME records in the same layout
  * (same offsets, separators at the same positions) scored by motif_struct as in pfmscan_hits_letters_f64_dev.
  *   hit <=> seq(p) > thr_seq and struct(p) > thr_struct            (both strict)
- * Both motifs are letters-only and share the width m (the join is on Start AND End).  The sequence letters pass runs
- * over everything, the structure letters are read at its hits only (k_letters_at).  Synchronises `stream`.
+ * Both motifs are letters-only and share the width m (the join is on Start AND End).  For a finite, selective thr_seq on a
+ * PFM up to 32 wide this is ONE launch: the integer-prefiltered letters kernel scores the structure letters of its own
+ * survivors (k_letters_cred<.., PAIR>).  Otherwise the sequence letters pass runs over everything and the structure
+ * letters are read at its hits only (k_letters_at), which synchronises `stream` in between.
  * Hit arrays and count as in pfmscan_hits_dev (d_hit_struct = the fp64 structure score). */
 int pfmscan_hits_pair_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif_seq,
                           const pfmscan_motif *motif_struct, const uint8_t *d_codes,

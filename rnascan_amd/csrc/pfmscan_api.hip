@@ -762,6 +762,22 @@ static int pair_core(pfmscan_ctx *ctx, const pfmscan_motif *mo_seq, const pfmsca
     if ((rc = check_and_fill(ctx, mo_st, d_codes2, nullptr, PFMSCAN_PROFILE_NONE, n_pos, a2))) return rc;
     a1.struct_pssm = a2.struct_pssm = nullptr;
     a1.profile = a2.profile = nullptr;
+    // the usual case -- a selective finite threshold on a PFM up to 32 wide -- is ONE launch: the integer-prefiltered letters
+    // kernel verifies the second stream for its own survivors (k_letters_cred<.., PAIR>); PFMSCAN_PAIR_TWO_PHASE=1: A/B
+    if (!std::getenv("PFMSCAN_PAIR_TWO_PHASE")) {
+        ScanArgs f = a1;
+        pfmscan_motif both1 = *mo_seq;
+        both1.d_struct = mo_st->d_letters;
+        fill_sink(f, &both1, sink, thr_seq, thr_struct);
+        f.codes2 = d_codes2;
+        f.letter_table2 = mo_st->d_letters;
+        hipError_t e1 = hipSuccess;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (launch_letters_cred(f, ctx->tune, st, &e1)) {
+            if (e1 != hipSuccess) return fail_hip(ctx, e1, "launch k_letters_cred (pair)");
+            return PFMSCAN_OK;
+        }
+    }
     const size_t counter_bytes = (size_t)HIT_SHARDS * HIT_COUNTER_STRIDE * 8;
     if ((rc = ensure(ctx, ctx->cand_count, counter_bytes))) return rc;
     std::vector<unsigned long long> counters((size_t)HIT_SHARDS * HIT_COUNTER_STRIDE);

@@ -41,6 +41,8 @@ struct ScanArgs {
     uint32_t *d_quad;            // DEVICE: room for that table (256 entries of up to 16 bytes), owned by the motif
     double *quad_thr;            // HOST: the threshold d_quad currently holds credits for (NaN: none), owned by the motif
     CredCache *cred_cache;       // HOST: owned by the motif
+    const uint8_t *codes2;       // two-FASTA combined scan fused into k_letters_cred: the second code stream (device) or null
+    const double *letter_table2; // ... and its letter table [m][8] (device); hits then need seq > thr_seq AND letters2 > thr_struct
     const double *h_letters;     // HOST: the letter table [m][8] (operand of the single-letter credits of k_letters_cred8)
     Cred8Cache *cred8_cache;     // HOST: owned by the motif
     uint32_t *d_cred8;           // DEVICE: [8][16] dwords, the packed credit table of cred8_cache->thr, owned by the motif
@@ -94,6 +96,9 @@ hipError_t launch_scan(const ScanArgs &a, const Tuning &t, hipStream_t stream, c
 // pfmscan_letters8.hip: fp64 letter hits through the single-letter integer prefilter (false: not applicable, take the exact
 // kernel); fp64 letter score of a SECOND code stream at the candidates of a letters pass (two-FASTA combined scan)
 bool launch_letters_cred8(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err);
+// pfmscan_kernels.hip: the integer-prefiltered hits kernel of 4-letter alphabets (false: not applicable -- dense threshold,
+// +inf cells, width > 32); with a.codes2 / a.letter_table2 set it verifies the second stream in the same launch
+bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err);
 // letters-only scans of PFMs wider than PFMSCAN_MAX_M: codes in LDS, the table streamed through LDS in 64-row slabs
 bool launch_wide_letters(const ScanArgs &a, hipStream_t stream, hipError_t *err);
 hipError_t launch_letters_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,

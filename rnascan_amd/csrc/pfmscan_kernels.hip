@@ -425,7 +425,11 @@ template <int NJ> struct CredEntry { typedef u32x4 type; };          // 3 or 4 r
 template <> struct CredEntry<2> { typedef u32x2 type; };
 template <> struct CredEntry<1> { typedef uint32_t type; };
 
-template <int NJ>
+// PAIR: the two-FASTA combined scan in ONE launch (rnascan.py:119-123, :416-434).  A survivor whose exact float32 sequence
+// score passes is scored right away on the SECOND code stream (a.codes2, a.letter_table2: the structure letters of the same
+// positions, fp64 sum as matrix.py:25-43) and is a hit only when that exceeds a.thr_struct too -- no candidate list, no
+// count read-back, no second launch.  The hit queue carries both scores (half as many slots: combined hits are rarer).
+template <int NJ, bool PAIR>
 __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const CredTable ct)
 {
     constexpr int W = 16;                              // windows per lane = one round per tile
@@ -442,8 +446,11 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     __shared__ __align__(16) double tbl[TROWS * 8];
     __shared__ __align__(16) uint32_t ctab[16 * (ESTR / 4)];
     __shared__ __align__(16) uint8_t cbuf[2][LET_TILE + CODE_HALO];
-    __shared__ uint32_t q_pos[NWAVE][WQ_CAP];          // positions in both queues are relative to the workgroup's first tile:
-    __shared__ float q_sc[NWAVE][WQ_CAP];
+    constexpr int QCAP = PAIR ? WQ_CAP / 2 : WQ_CAP;
+    __shared__ __align__(16) double tbl2[PAIR ? TROWS * 8 : 1];      // the second stream's letter table (rows m .. are zeros)
+    __shared__ __align__(8) double q_st[PAIR ? NWAVE : 1][PAIR ? QCAP : 1];
+    __shared__ uint32_t q_pos[NWAVE][QCAP];            // positions in both queues are relative to the workgroup's first tile:
+    __shared__ float q_sc[NWAVE][QCAP];
     __shared__ int q_n[NWAVE], snap[2][NWAVE];
     __shared__ unsigned long long s_base;
     __shared__ uint32_t sv_pos[NWAVE][128];            // 4-byte entries keep the workgroup under 20 KB of LDS = 8 per CU (26 KB: 6);
@@ -459,6 +466,8 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     cs.fetch(a.codes, first, n_pos);
     // rows m .. are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
     for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
+    if (PAIR)
+        for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl2[i] = i < m * 8 ? a.letter_table2[i] : 0.0;
     for (int i = threadIdx.x; i < 16 * (ESTR / 4); i += BLOCK) ctab[i] = (i % (ESTR / 4)) < 8 ? ct.d[i / (ESTR / 4)][i % (ESTR / 4)] : 0u;
     if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
     cs.park(cbuf[0]);
@@ -471,19 +480,20 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
     unsigned long long *counter = a.hit_count + shard * HIT_COUNTER_STRIDE;
     uint32_t *my_pos = q_pos[wave];
     float *my_sc = q_sc[wave];
+    double *my_st = q_st[PAIR ? wave : 0];
 
-    auto store_hit = [&](unsigned long long slot, int64_t pos, float sc) {
+    auto store_hit = [&](unsigned long long slot, int64_t pos, float sc, double st) {
         if ((int64_t)slot < a.capacity) {             // capacity is per shard
             a.hit_pos[shard_off + slot] = pos + a.pos_offset;
             if (a.hit_seq) a.hit_seq[shard_off + slot] = sc;
-            if (a.hit_struct) a.hit_struct[shard_off + slot] = (double)sc;
+            if (a.hit_struct) a.hit_struct[shard_off + slot] = PAIR ? st : (double)sc;
         }
     };
     auto drain = [&](unsigned long long base, int n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i = lane; i < n; i += 64) store_hit(base + i, first + (int64_t)my_pos[i], my_sc[i]);
+        for (int i = lane; i < n; i += 64) store_hit(base + i, first + (int64_t)my_pos[i], my_sc[i], PAIR ? my_st[i] : 0.0);
         if (lane == 0) q_n[wave] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (qn_ub + cnt > WQ_CAP) {                    // room for a hit per lane in the hit queue
+        if (qn_ub + cnt > QCAP) {                      // room for a hit per lane in the hit queue
             wave_flush();
             qn_ub = 0;
         }
@@ -530,10 +540,25 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
                 }
             }
             const float f = (float)sc;
-            if ((double)f > a.thr_seq) {
+            bool ok = (double)f > a.thr_seq;
+            double st = 0.0;
+            if (PAIR && ok) {                          // the structure letters of the same window: fp64 sum, fp64 compare
+                uint32_t raw2[NJ + 1];
+#pragma unroll
+                for (int k = 0; k < NJ + 1; ++k) raw2[k] = load_codes4(a.codes2, al + 4 * k, n_pos);
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) {
+                    const uint32_t cw = __builtin_amdgcn_alignbyte(raw2[k + 1], raw2[k], (uint32_t)(p & 3));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) st += tbl2[(4 * k + b) * 8 + ((cw >> (8 * b)) & 7u)];      // rows m .. 4 NJ - 1 are zeros
+                }
+                ok = st > a.thr_struct;
+            }
+            if (ok) {
                 const int slot = atomicAdd(&q_n[wave], 1);     // LDS
                 my_pos[slot] = (uint32_t)(p - first);
                 my_sc[slot] = f;
+                if (PAIR) my_st[slot] = st;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -631,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
             most = most > nq[k] ? most : nq[k];
         }
         qn_ub = nq[wave];
-        if (most >= WQ_CAP / 2 || (!more && total > 0)) {          // uniform: every thread read the same snapshot
+        if (most >= QCAP / 2 || (!more && total > 0)) {            // uniform: every thread read the same snapshot
             if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)total);
             __syncthreads();
             drain(s_base + (unsigned long long)before, nq[wave]);
@@ -1414,7 +1439,7 @@ static int walk_tiles(int64_t ntiles, const Tuning &t)
 }
 
 // false when the motif has +inf / NaN two-letter sums (the fp32 prefilter handles those)
-static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
+bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
     if (!(a.hits && !a.f64_hits && a.pair_table && a.h_pairsum && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
     constexpr int CRED_TILE = BLOCK * 16;              // k_letters_cred: 16 windows per lane
@@ -1463,16 +1488,15 @@ static bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t 
     b.tiles_per_block = walk_tiles(ntiles, t);
     if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
     const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
+#define CRED_CASE(N) case N: if (b.codes2) hipLaunchKernelGGL((k_letters_cred<N, true>), dim3(g), dim3(BLOCK), 0, stream, b, ct); \
+                             else hipLaunchKernelGGL((k_letters_cred<N, false>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
     switch (nj) {
-    case 1: hipLaunchKernelGGL((k_letters_cred<1>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    case 2: hipLaunchKernelGGL((k_letters_cred<2>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    case 3: hipLaunchKernelGGL((k_letters_cred<3>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    case 4: hipLaunchKernelGGL((k_letters_cred<4>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    case 5: hipLaunchKernelGGL((k_letters_cred<5>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    case 6: hipLaunchKernelGGL((k_letters_cred<6>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    case 7: hipLaunchKernelGGL((k_letters_cred<7>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
-    default: hipLaunchKernelGGL((k_letters_cred<8>), dim3(g), dim3(BLOCK), 0, stream, b, ct); break;
+    CRED_CASE(1) CRED_CASE(2) CRED_CASE(3) CRED_CASE(4) CRED_CASE(5) CRED_CASE(6) CRED_CASE(7)
+    default: if (b.codes2) hipLaunchKernelGGL((k_letters_cred<8, true>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+             else hipLaunchKernelGGL((k_letters_cred<8, false>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+             break;
     }
+#undef CRED_CASE
     *err = hipGetLastError();
     return true;
 }
