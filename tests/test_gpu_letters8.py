@@ -2,7 +2,6 @@
 matrix.py:25-43 + rnascan.py:263) and the two-FASTA combined scan (rnascan.py:119-123, :416-434), through the C ABI,
 against the CPU oracle, the reference's `_py_calculate` goldens and the oracle-backed engine of the CLI."""
 import io
-import os
 
 import numpy as np
 import pytest
