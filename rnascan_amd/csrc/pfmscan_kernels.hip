@@ -1434,7 +1434,10 @@ static hipError_t allow_full_lds(const void *kern, std::atomic<uint64_t> &done)
 // 0.400 -> 0.355 (tools/gpu_sweep_tpb.sh).
 static int walk_tiles(int64_t ntiles, const Tuning &t)
 {
-    const int64_t per = (int64_t)t.n_cu * 24;
+    // round 4: ~18 per CU.  Every workgroup ends with a serial tail -- the last survivors' exact scores (an L2 round trip), the
+    // returning atomic, the drain -- so fewer, longer workgroups win once there ARE hits: C2 -m 6 0.1065 (12 tiles, 24 per CU)
+    // -> 0.0956 (16 tiles, 18 per CU), no hits 0.0745 -> 0.0746, w = 18 0.1453 -> 0.1441; 20+ tiles lose again (no hits 0.078)
+    const int64_t per = (int64_t)t.n_cu * 18;
     return (int)std::min<int64_t>(32, std::max<int64_t>(1, (ntiles + per / 2) / per));
 }
 

@@ -328,7 +328,7 @@ void build_cred8(const double *h_letters, int m, double thr, Cred8Cache *cc)
 // tiles one workgroup walks: ~24 workgroups per CU in the grid (see walk_tiles in pfmscan_kernels.hip)
 static int walk_tiles8(int64_t ntiles, const Tuning &t)
 {
-    const int64_t per = (int64_t)t.n_cu * 24;
+    const int64_t per = (int64_t)t.n_cu * 18;
     return (int)std::min<int64_t>(32, std::max<int64_t>(1, (ntiles + per / 2) / per));
 }
 
