@@ -101,11 +101,19 @@ def _guess_seq_type(args):
     sys.exit(1)
 
 
-def profile_type(args, struct_pssm):
-    """the device storage of the profile rows for this run (scanner.pick_profile_dtype), announced once on stderr"""
+def profile_type(args, struct_pssm, stored=None):
+    """the device storage of the profile rows for this run (scanner.pick_profile_dtype), announced once on stderr.
+    ``stored``: the dtype of a packed profile store that is the input -- float32 rows ARE the input then: they are scanned
+    as they are whatever the PFM's bound says (nothing is rounded on the way, and widening them would change no score)"""
     got = getattr(args, "_profile_type", None)
     if got is None:
-        got, bound = scanner.pick_profile_dtype(getattr(args, "profile_dtype", "auto"), struct_pssm)
+        asked = getattr(args, "profile_dtype", "auto")
+        if stored is not None and np.dtype(stored) == np.float32 and asked != "float32":
+            args._profile_type = np.float32
+            fasta.eprint("Averaged-structure profiles are stored as float32 on the device (the packed store holds float32 rows: "
+                         "they are the input and are scanned as they are)")
+            return np.float32
+        got, bound = scanner.pick_profile_dtype(asked, struct_pssm)
         args._profile_type = got
         how = "as asked" if getattr(args, "profile_dtype", "auto") != "auto" else \
             ("worst-case storage error %.1e < %.0e" % (bound, scanner.FLOAT32_STORAGE_BUDGET) if got is np.float32 else
@@ -354,7 +362,7 @@ def main(argv=None, engine=None, out=None):
     if seq_type == "RNASS" and not args.testseq and os.path.isdir(struct_source) and not os.path.isdir(seq_source):
         # sequence FASTA + averaged-structure directory (or packed store): one fused kernel pass per batch (configs 3, 5).
         # Only an index of both sides is held; a batch reads its own records and the profiles of those records.
-        ptype = profile_type(args, struct_pssm)
+        ptype = profile_type(args, struct_pssm, store.ProfileStore(struct_source).dtype if store.is_store(struct_source) else None)
         fasta.eprint("Scanning sequences ")
         recs = fasta.open_lazy(seq_source)
         fasta.eprint("Processed %d sequences" % len(recs))

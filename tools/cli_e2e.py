@@ -137,6 +137,11 @@ if NLIB:
     if RBIG and BIGSTORE:
         runs.append(("big library: %d pairs, seq + struct (store) -m 6" % NLIB,
                      ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", "--profile-dtype", "float32", big, bigsd]))
+        runs.append(("big library: the same with DEFAULT flags (float32 store scanned as it is)",
+                     ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", big, bigsd]))
+        runs.append(("big: seq + struct (store) -m -9 with DEFAULT flags",
+                     ["-p", os.path.join(DATA, "SLBP_pfm_assembled_normalized_seq.txt"), "-q",
+                      os.path.join(DATA, "SLBP_pfm_assembled_normalized_struct.txt"), "-C", "0.01", "-u", "-m", " -9", big, bigsd]))
 for name, argv in runs:
     nrec = RBIG if name.startswith("big") else R
     nmot = NLIB if "library" in name else 1
