@@ -151,6 +151,28 @@ def pmc_entry(workload):
     return {}
 
 
+def live_mixed_floor(records, length):
+    """tools/hbm_mixed `quick` as a child process on the same GPU, right after the timed region: the fastest of its
+    read+write forms is what THIS box's memory system gives the headline's byte mix (29 B in + 12 B out per position,
+    nothing scored).  None when the tool is not built (rnascan_amd/build.py: build_floor_tool)."""
+    import subprocess
+    exe = os.path.join(REPO, "tools", "hbm_mixed")
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if not os.access(exe, os.X_OK) or os.environ.get("PFMSCAN_BENCH_NO_FLOOR") or profiled:     # no child processes under a profiler
+        return None
+    try:
+        out = subprocess.run([exe, str(records), str(length), "quick"], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    for ln in out.stdout.splitlines():
+        if ln.startswith("floor_ms "):
+            f = ln.split()
+            return {"ms": float(f[1]), "tb_per_s": float(f[3]), "bytes": float(f[5]),
+                    "source": "tools/hbm_mixed %d %d quick, run by this bench.py on the same GPU after the timed region" % (records, length),
+                    "note": "fastest of 4 read+write forms (vector-load tiles, LDS-DMA tiles); whole tiles of 8192 positions"}
+    return None
+
+
 def library_roofline(info, windows, n_motifs, width, records, length, kernel_ms, n_hits, rate_seq):
     """k_library is bound by LDS look-ups, not by HBM: every window x motif group needs ceil(w/2) 16-byte table entries
     (ds_read_b128, 256 B/clk/CU).  ``achieved`` = the bytes phase A's look-ups MOVE per second (entries of 12 or 8
@@ -685,11 +707,15 @@ def main():
         if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32":
             # the same byte mix (29 B in + 12 B out per position) moved by a program that scores nothing
             # (tools/hbm_mixed.hip, measured on this chip in round 4): what the memory system gives this access pattern
+            live = live_mixed_floor(args.records, args.length) if (rank == 0 and world == 1) else None
             floor = pmc_entry("c3_mixed_floor")
-            if floor.get("records") == args.records and floor.get("length") == args.length:
+            if live is not None:
+                result["roofline"]["mixed_read_write_floor"] = dict(live, frac_of_floor=live["ms"] / kernel_ms, kernel_over_floor=kernel_ms / live["ms"])
+            elif floor.get("records") == args.records and floor.get("length") == args.length:
                 result["roofline"]["mixed_read_write_floor"] = {
                     "ms": floor["floor_ms"], "tb_per_s": floor["floor_tb_per_s"], "frac_of_floor": floor["floor_ms"] / kernel_ms,
-                    "source": floor["source"], "note": "stored measurement of tools/hbm_mixed (its fastest form), not taken in this run"}
+                    "source": floor["source"], "note": "stored measurement of tools/hbm_mixed (its fastest form) on ANOTHER box, not taken in this run "
+                                                       "(tools/hbm_mixed is not built here): boxes of the pool differ by up to 10 % on it"}
         if traffic is not None:
             result["roofline"]["traffic_pmc_round"] = pmc_entry("c2" if seq_only else "c3").get("round")
         if dist is not None:

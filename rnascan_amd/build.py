@@ -68,5 +68,16 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_floor_tool(force=False):
+    """tools/hbm_mixed: the microbenchmark that moves the headline kernel's byte mix without scoring (bench.py runs its
+    `quick` form beside the headline so that `roofline.mixed_read_write_floor` is a measurement of the SAME box)."""
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    src, exe = os.path.join(tools, "hbm_mixed.hip"), os.path.join(tools, "hbm_mixed")
+    if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call([hipcc_path(), "-O3", "--offload-arch=gfx950", src, "-o", exe])
+    return exe
+
+
 if __name__ == "__main__":
+    build_floor_tool(force="--force" in sys.argv)
     print(build_lib(force="--force" in sys.argv, verbose=True))

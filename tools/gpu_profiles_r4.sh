@@ -21,6 +21,7 @@ run bench_c2_w4_hits_m2 --workload c2 --width 4 --mode hits --minscore-seq 2 --n
 run bench_c4_shard_125k --records 125000 --no-cpu-baseline --no-secondary
 tools/hbm_mixed > $OUT/hbm_mixed_ceiling.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
+export PFMSCAN_BENCH_NO_FLOOR=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_c3 -- python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 200 > $ROOT/$OUT/trace_c3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_c5 -- python3 $ROOT/bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline > $ROOT/$OUT/trace_c5.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_c2_hits -- python3 $ROOT/bench.py --workload c2 --width 8 --mode hits --minscore-seq 6 --no-cpu-baseline --steps 200 > $ROOT/$OUT/trace_c2_hits.log 2>&1

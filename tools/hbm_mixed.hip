@@ -10,12 +10,13 @@
 //   lds      the same with the tile staged through LDS by LDS-DMA (global_load_lds_dwordx4), as k_profile stages it
 //   read     inputs only            write    outputs only
 // swept over tile sizes and resident workgroups per CU.
-//   hipcc -O3 --offload-arch=gfx950 tools/hbm_mixed.hip -o tools/hbm_mixed && tools/hbm_mixed [records] [length]
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_mixed.hip -o tools/hbm_mixed && tools/hbm_mixed [records] [length] [quick]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
@@ -131,17 +132,22 @@ static double time_ms(F launch, int iters)
     return t[t.size() / 2];
 }
 
+static double g_best_rw = 1e30;       // fastest read+write form seen
+static bool g_quick = false;          // "quick": read+write forms only (bench.py takes the floor of ITS box from this)
+
 template <int TILE, int BLOCK, bool NT, int ST = 0>
 static void run_copy(const char *name, Args a, double bytes_r, double bytes_w, unsigned short_grid = 0)
 {
     const unsigned grid = short_grid ? short_grid : (unsigned)(a.n_pos / TILE);
     struct { const char *what; int r, w; } modes[] = {{"read+write", 1, 1}, {"read only", 1, 0}, {"write only", 0, 1}};
     for (auto &md : modes) {
+        if (g_quick && !(md.r && md.w)) continue;
         Args b = a;
         b.do_read = md.r;
         b.do_write = md.w;
         const double ms = time_ms([&] { hipLaunchKernelGGL((k_copy<TILE, BLOCK, NT, ST>), dim3(grid), dim3(BLOCK), 0, 0, b); }, 20);
         const double gb = (md.r ? bytes_r : 0) + (md.w ? bytes_w : 0);
+        if (md.r && md.w && ms < g_best_rw) g_best_rw = ms;
         std::printf("%-34s %-10s %7.3f ms  %6.2f TB/s\n", name, md.what, ms, gb / ms * 1e-9);
     }
 }
@@ -154,11 +160,13 @@ static void run_lds(const char *name, Args a, double bytes_r, double bytes_w)
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds<TILE, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     struct { const char *what; int r, w; } modes[] = {{"read+write", 1, 1}, {"read only", 1, 0}};
     for (auto &md : modes) {
+        if (g_quick && !(md.r && md.w)) continue;
         Args b = a;
         b.do_read = md.r;
         b.do_write = md.w;
         const double ms = time_ms([&] { hipLaunchKernelGGL((k_lds<TILE, BLOCK>), dim3(grid), dim3(BLOCK), lds, 0, b); }, 20);
         const double gb = (md.r ? bytes_r : 0) + (md.w ? bytes_w : 0);
+        if (md.r && md.w && ms < g_best_rw) g_best_rw = ms;
         std::printf("%-34s %-10s %7.3f ms  %6.2f TB/s\n", name, md.what, ms, gb / ms * 1e-9);
     }
 }
@@ -166,6 +174,7 @@ static void run_lds(const char *name, Args a, double bytes_r, double bytes_w)
 int main(int argc, char **argv)
 {
     const int64_t records = argc > 1 ? std::atoll(argv[1]) : 100000, length = argc > 2 ? std::atoll(argv[2]) : 3000;
+    g_quick = argc > 3 && std::strcmp(argv[3], "quick") == 0;
     int64_t n_pos = records * (length + 1);
     n_pos -= n_pos % 8192;                                      // whole tiles for every tile size below
     Args a;
@@ -180,6 +189,14 @@ int main(int argc, char **argv)
     const double br = (double)n_pos * 29, bw = (double)n_pos * 12;
     std::printf("positions %lld: %.3f GB read + %.3f GB written = %.3f GB per pass (C3's launch moves 12.287 GB)\n", (long long)n_pos,
                 br * 1e-9, bw * 1e-9, (br + bw) * 1e-9);
+    if (g_quick) {                                              // the forms that were fastest on every box so far
+        run_copy<2048, 256, true>("copy  tile 2048, nt loads", a, br, bw);
+        run_lds<1024, 256>("lds-dma tile 1024 (29 KB)", a, br, bw);
+        run_lds<2048, 256>("lds-dma tile 2048 (58 KB)", a, br, bw);
+        run_lds<1024, 128>("lds-dma tile 1024, 128 threads", a, br, bw);
+        std::printf("floor_ms %.4f tb_per_s %.3f bytes %.0f\n", g_best_rw, (br + bw) / g_best_rw * 1e-9, br + bw);
+        return 0;
+    }
     run_copy<1024, 256, true>("copy  tile 1024, nt loads", a, br, bw);
     run_copy<2048, 256, true>("copy  tile 2048, nt loads", a, br, bw);
     run_copy<4096, 256, true>("copy  tile 4096, nt loads", a, br, bw);
@@ -195,5 +212,6 @@ int main(int argc, char **argv)
     run_lds<1024, 128>("lds-dma tile 1024, 128 threads", a, br, bw);
     const double best_hint = (br + bw) / 8e12 * 1e3;
     std::printf("at the 8 TB/s spec peak the pass would take %.3f ms\n", best_hint);
+    std::printf("floor_ms %.4f tb_per_s %.3f bytes %.0f\n", g_best_rw, (br + bw) / g_best_rw * 1e-9, br + bw);
     return 0;
 }

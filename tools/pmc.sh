@@ -9,6 +9,7 @@ VARIANT=${2:-}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export PFMSCAN_BENCH_NO_FLOOR=1      # bench.py starts no child process (its live floor measurement) under the profiler
 for kv in $VARIANT; do export $kv; done
 i=0
 for counters in \
