@@ -169,7 +169,8 @@ def live_mixed_floor(records, length):
             f = ln.split()
             return {"ms": float(f[1]), "tb_per_s": float(f[3]), "bytes": float(f[5]),
                     "source": "tools/hbm_mixed %d %d quick, run by this bench.py on the same GPU after the timed region" % (records, length),
-                    "note": "fastest of 4 read+write forms (vector-load tiles, LDS-DMA tiles); whole tiles of 8192 positions"}
+                    "note": "fastest of 4 read+write forms (vector-load tiles, LDS-DMA tiles) in 3 rounds, each the median of 5 x 20 passes; "
+                            "the figure moves by up to 10 % from one minute to the next on one box, like the kernel's own time"}
     return None
 
 
@@ -431,6 +432,11 @@ def main():
                          "stream beside the scan of the previous chunk, hits sorted and copied back.  Reports windows/s and the "
                          "PCIe rate; never the headline value")
     ap.add_argument("--chunk-positions", type=int, default=1 << 24, help="chunk of --from-host (stream positions)")
+    ap.add_argument("--placement", choices=["tuned", "plain", "torch"], default="tuned",
+                    help="where the resident arrays (codes, profile, both score arrays) lie in HBM.  tuned: pfmscan_place_alloc -- the "
+                         "library takes chunks of device memory, measures which disturb each other (shared DRAM banks) and gives the arrays "
+                         "of the scan chunks that do not (DESIGN.md section 3; the same kernel runs 2.2 ms or 1.96 ms depending on this); plain: "
+                         "the same allocator without the measurement; torch: torch's caching allocator, wherever that puts them")
     ap.add_argument("--hit-rate", type=float, default=1e-4, help="target combined hit rate of the auto structure threshold (SURVEY 8d C5)")
     args = ap.parse_args()
     if args.minscore is not None:
@@ -494,6 +500,17 @@ def main():
         tabs = [make_pssms(args.width, args.variant, seed=1000 + k) for k in range(args.motifs)]      # seeds 1000 + k
         lib_T, lib_P = np.stack([t for t, _ in tabs]), np.stack([p for _, p in tabs])
         library = ctx.library(None if struct_lib else lib_T, lib_P)
+    # the resident arrays, placed BEFORE anything else takes device memory (more candidates to choose from)
+    n_pos = args.records * (args.length + 1)
+    prow = 7 * (8 if args.profile_dtype == "float64" else 4)
+    placed, placement = None, {"mode": "torch"}
+    if args.placement != "torch" and not args.from_host:
+        try:
+            t_pl = time.perf_counter()
+            placed = ctx.place_alloc([n_pos * prow, n_pos * 8, n_pos * 4, n_pos], plain=args.placement == "plain")
+            placement = {"mode": args.placement, "seconds": round(time.perf_counter() - t_pl, 3), "note": ctx.place_note()}
+        except Exception as exc:                     # e.g. no virtual memory API on this driver: the arrays come from torch instead
+            placement = {"mode": "torch", "note": "pfmscan_place_alloc failed (%s); torch's allocator was used" % exc}
     codes, profile, n_pos = make_stream(torch, dev, args.records, args.length, 20240601 + rank,
                                         foreign=0.001 if args.variant == "inf" else 0.0,
                                         zero_snap=args.variant == "inf")
@@ -501,10 +518,24 @@ def main():
     if args.profile_dtype == "float64":
         profile = profile.double()
         ptype = _lib.PROFILE_F64
-    # zero-filled (touched) outputs: first-touch of fresh device pages would otherwise
-    # land in the first kernel launches and skew the per-kernel average rocprof reports
-    out_seq = torch.zeros(n_pos, dtype=torch.float32, device=dev)
-    out_st = torch.zeros(n_pos, dtype=torch.float64, device=dev)
+    if placed is not None:
+        raw = [torch.as_tensor(a, device=dev) for a in placed]          # uint8 views of the placed ranges, no copy
+        assert all(t.data_ptr() == a.ptr for t, a in zip(raw, placed))
+        p_new = raw[0].view(profile.dtype).view(n_pos, 7)
+        p_new.copy_(profile)
+        c_new = raw[3]
+        c_new.copy_(codes)
+        del profile, codes
+        torch.cuda.empty_cache()
+        profile, codes = p_new, c_new
+        out_st, out_seq = raw[1].view(torch.float64), raw[2].view(torch.float32)
+        out_st.zero_()
+        out_seq.zero_()
+    else:
+        # zero-filled (touched) outputs: first-touch of fresh device pages would otherwise
+        # land in the first kernel launches and skew the per-kernel average rocprof reports
+        out_seq = torch.zeros(n_pos, dtype=torch.float32, device=dev)
+        out_st = torch.zeros(n_pos, dtype=torch.float64, device=dev)
     windows = args.records * (args.length - args.width + 1)
     # a real (non-null) torch stream: the ABI reads stream NULL as "the ctx's own
     # stream", and the HIP events below must sit on the stream the kernel runs on
@@ -694,6 +725,7 @@ def main():
                 "hits_per_step": n_hits, "hits_per_step_all_ranks": sum(h for h in rank_hits if h is not None) if n_hits is not None else None,
                 "hit_rate": None if n_hits is None else n_hits / (windows * n_motifs),
                 "sharding": "records, no collective",
+                "placement": placement,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

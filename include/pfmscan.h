@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 6
+#define PFMSCAN_ABI_VERSION 7
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -496,6 +496,22 @@ int pfmscan_time_scan_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
                           int profile_dtype, int64_t n_pos, float *d_out_seq,
                           double *d_out_struct, void *stream, int warmup,
                           int iters, double *avg_ms);
+
+/* ---- device arrays of one scan, placed together ------------------------------------
+ * No counterpart in the reference (its arrays are numpy arrays in host memory: rnascan.py:296-301, matrix.py:59-62).
+ * The arrays one all-scores scan walks in lock-step -- codes, profile rows, the two score arrays -- run up to 12 % faster
+ * on MI355X when they lie in parts of HBM that do not share DRAM banks (rnascan_amd/csrc/pfmscan_place.hip).
+ * pfmscan_place_alloc allocates n_arrays (1..8) device arrays of bytes[r] each TOGETHER: it takes chunks of physical memory
+ * through the HIP virtual memory API, measures which chunks disturb each other, gives every array the chunks that disturb the
+ * chunks the other arrays use at the same fraction of the pass least, and returns ptrs[r] (contiguous, 2 MB aligned, contents
+ * undefined, usable like any device pointer with every *_dev entry point).  PFMSCAN_PLACE_PLAIN in `flags` (or in the
+ * environment) skips the measurement.  pfmscan_place_free takes ptrs[0] of a set and frees the whole set after a device
+ * synchronise; pfmscan_ctx_destroy frees what is left.  pfmscan_place_note: one line about the last allocation (candidates,
+ * measured pair times, weighted disturbance chosen / driver order).  Results of scans never depend on placement. */
+#define PFMSCAN_PLACE_PLAIN 1
+int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, void **ptrs, int flags);
+int pfmscan_place_free(pfmscan_ctx *ctx, void *first_array);
+const char *pfmscan_place_note(const pfmscan_ctx *ctx);
 
 #ifdef __cplusplus
 }

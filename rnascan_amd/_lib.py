@@ -22,7 +22,7 @@ NCODE = 8
 NSTRUCT = 7
 MAX_M = 64            # widest PFM of the tuned kernels and of PFM libraries
 MAX_WIDTH = 4096      # widest PFM accepted (wider than MAX_M: the plain rolled-loop kernel)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -38,6 +38,7 @@ SYMBOLS = [
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
     "pfmscan_hits_pair_dev", "pfmscan_stage_codes2", "pfmscan_hits_pair_staged", "pfmscan_hits_pair_host", "pfmscan_round_decimals",
     "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_upload_source_file_checked", "pfmscan_fasta_lone_cr", "pfmscan_count_bytes", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
+    "pfmscan_place_alloc", "pfmscan_place_free", "pfmscan_place_note",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -133,6 +134,10 @@ def load():
     L.pfmscan_upload_source_file_checked.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_char_p, i64, i64, i64, i64]
     L.pfmscan_fasta_lone_cr.argtypes = [vp, i64, ctypes.POINTER(i32), i32]
     L.pfmscan_count_bytes.argtypes = [vp, i64, vp, i32]
+    L.pfmscan_place_alloc.argtypes = [vp, i32, vp, vp, i32]
+    L.pfmscan_place_free.argtypes = [vp, vp]
+    L.pfmscan_place_note.argtypes = [vp]
+    L.pfmscan_place_note.restype = ctypes.c_char_p
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
     L.pfmscan_fasta_ids.argtypes = [vp, vp, vp, i64, vp, vp, ctypes.POINTER(i32)]
     L.pfmscan_gather_spans.argtypes = [vp, vp, i64, i32, vp, i64, ctypes.POINTER(i64)]
@@ -150,7 +155,7 @@ def load():
     L.pfmscan_tsv_format.argtypes = [ctypes.POINTER(TsvColumn), i32, i64, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i32), i32]
     for name in SYMBOLS:          # every other entry point returns a status
         if name not in ("pfmscan_ctx_destroy", "pfmscan_motif_destroy", "pfmscan_last_error", "pfmscan_library_destroy",
-                        "pfmscan_staged_positions"):
+                        "pfmscan_staged_positions", "pfmscan_place_note"):
             getattr(L, name).restype = i32
     L.pfmscan_staged_positions.restype = i64
     if L.pfmscan_abi_version() != ABI_VERSION:
@@ -372,6 +377,21 @@ def tsv_format(columns, n_rows, first_match_id=-1, threads=0, estimate=None, scr
         return [view[int(pieces[2 * k]):int(pieces[2 * k] + pieces[2 * k + 1])] for k in range(n_pieces.value)]
 
 
+PLACE_PLAIN = 1
+
+
+class PlacedArray(object):
+    """one array of a set of Context.place_alloc: a raw device range that outlives this object (the set is freed by
+    Context.place_free(first array) or with the context)"""
+
+    def __init__(self, ctx, ptr, nbytes, first):
+        self.ctx, self.ptr, self.nbytes, self.first = ctx, ptr, nbytes, first
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+
 class Context(object):
     """One device context (one per GPU / per host thread)."""
 
@@ -415,6 +435,23 @@ class Context(object):
 
     def synchronize(self):
         self._check(self._L.pfmscan_synchronize(self._h))
+
+    # -- device arrays of one scan, placed together (pfmscan_place_alloc) ------------
+    def place_alloc(self, sizes, plain=False):
+        """device arrays of ``sizes`` bytes that one scan walks in lock-step, in parts of HBM that do not share DRAM banks
+        (include/pfmscan.h: pfmscan_place_alloc); returns a list of PlacedArray (``.ptr``, ``.nbytes``, and
+        ``__cuda_array_interface__``: ``torch.as_tensor(a, device=...)`` views it as uint8 without a copy)"""
+        n = len(sizes)
+        b = (ctypes.c_int64 * n)(*[int(x) for x in sizes])
+        out = (ctypes.c_void_p * n)()
+        self._check(self._L.pfmscan_place_alloc(self._h, n, b, out, PLACE_PLAIN if plain else 0))
+        return [PlacedArray(self, int(out[r]), int(sizes[r]), r == 0) for r in range(n)]
+
+    def place_free(self, first):
+        self._check(self._L.pfmscan_place_free(self._h, ctypes.c_void_p(first.ptr if isinstance(first, PlacedArray) else int(first))))
+
+    def place_note(self):
+        return (self._L.pfmscan_place_note(self._h) or b"").decode()
 
     # -- PSSM operands ----------------------------------------------------------
     def motif(self, letter_table=None, struct_pssm=None):

@@ -125,6 +125,7 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
                       &ctx->pipe_profile[0], &ctx->pipe_profile[1], &ctx->codes2})
         release(*b);
     upload_release(ctx);
+    place_release_all(ctx);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
         if (ctx->pipe_scanned[i]) (void)hipEventDestroy(ctx->pipe_scanned[i]);

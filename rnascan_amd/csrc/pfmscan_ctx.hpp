@@ -2,6 +2,7 @@
 // shares (error reporting, device scratch).  Not installed.
 #pragma once
 #include <string>
+#include <vector>
 
 #include "pfmscan_internal.hpp"
 
@@ -68,6 +69,9 @@ struct pfmscan_ctx {
     bool staged_codes = false, staged_profile = false, staged_codes2 = false;
     // candidate-then-verify: the last full letters pass was selective -> skip the pilot next time
     bool two_phase_hot = false;
+    // pfmscan_place.hip: sets of arrays placed together (PlaceSet *), and a line about the last allocation
+    std::vector<void *> place_sets;
+    std::string place_note;
 };
 
 namespace pfmscan {
@@ -85,6 +89,7 @@ int finish_sorted_hits(pfmscan_ctx *ctx, bool has_seq, bool has_struct, int64_t 
 // pfmscan_upload.hip: asynchronous host -> device copy on `st`; the source may be reused when it returns
 int upload(pfmscan_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t st);
 void upload_release(pfmscan_ctx *ctx);
+void place_release_all(pfmscan_ctx *ctx);   // pfmscan_place.hip
 inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 }  // namespace pfmscan

@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the
 committed goldens.  Integer/position work and float32 sequence scores are
 bit-exact; structure scores within 1e-6 absolute (BASELINE.json north_star)."""
+import os
 import numpy as np
 import pytest
 
@@ -537,4 +538,91 @@ def test_staged_length_follows_the_library_not_a_stale_copy(ctx, oracle):
     ctx.hits_pipeline_host(motif, large.codes, None, 2.0, -np.inf, 4096)      # leaves nothing staged
     with pytest.raises(ValueError):
         ctx.scan_staged(motif)
+    motif.close()
+
+
+FIXED_WIDTHS = list(range(4, 19))          # widths with an unrolled instantiation of k_profile (pfmscan_profile_fixed.hip: launch_profile_fixed)
+
+
+@pytest.mark.parametrize("m", FIXED_WIDTHS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("has_seq", [True, False])
+@pytest.mark.parametrize("inf_frac", [0.0, 0.1])
+def test_fixed_width_profile_kernel_equals_the_generic_one(ctx, oracle, monkeypatch, m, dtype, has_seq, inf_frac):
+    """k_profile_fixed (the PFM width a compile-time constant: straight-line row loop, loads requested a step ahead) performs
+    the generic kernel's operations in the generic kernel's order: the same bits, structure scores included, on a stream of
+    several tiles with a ragged end, NaN / inf cells in the PSSM (the per-row nan_to_num variant) and in the profile (the exact
+    re-run of a window whose fast sum came out non-finite)"""
+    rng = np.random.default_rng(1000 * m + 10 * int(has_seq) + int(inf_frac * 10) + (dtype == np.float64))
+    s = rand_stream(rng, 9, 0, 1500, dtype=dtype)
+    bad = rng.integers(0, s.n_pos, size=12)
+    s.profile[bad[:6], rng.integers(0, 7, size=6)] = np.nan
+    s.profile[bad[6:], rng.integers(0, 7, size=6)] = np.inf
+    T = rand_table(rng, m, 4, inf_frac=inf_frac / 3) if has_seq else None
+    P = rand_struct_pssm(rng, m, inf_frac=inf_frac)
+    motif = ctx.motif(T, P)
+    codes = s.codes if has_seq else None
+    monkeypatch.setenv("PFMSCAN_PROFILE_FIXED_MIN", "0")          # every instantiation, also the widths the launcher leaves to the generic kernel
+    fixed_seq, fixed_st = ctx.scan_host(motif, codes, s.profile)
+    monkeypatch.setenv("PFMSCAN_PROFILE_GENERIC", "1")
+    gen_seq, gen_st = ctx.scan_host(motif, codes, s.profile)
+    monkeypatch.delenv("PFMSCAN_PROFILE_GENERIC")
+    motif.close()
+    assert np.array_equal(fixed_st.view(np.uint64), gen_st.view(np.uint64))
+    assert_struct_close(fixed_st, oracle.stream_struct(s.profile, P))
+    if has_seq:
+        assert np.array_equal(fixed_seq.view(np.uint32), gen_seq.view(np.uint32))
+        assert_f32_bits_equal(fixed_seq, oracle.stream_seq(s.codes, T))
+    else:
+        assert fixed_seq is None and gen_seq is None
+
+
+def test_placed_arrays_hold_what_is_written_and_scan_like_any_other(ctx, oracle):
+    """pfmscan_place_alloc (include/pfmscan.h): sets of device arrays in chunks of physical memory chosen by measurement.  The
+    arrays are ordinary device memory: what is written is read back, a scan on them gives the oracle's scores, and -- the hazard
+    the module's note on address ranges is about -- sets allocated AFTER a set was freed are intact too (on ROCm 7.2 a reused
+    address range read back other bytes; the ranges are therefore never reused)."""
+    import torch
+    from rnascan_amd import _lib
+    rng = np.random.default_rng(5)
+    m = 12
+    s = rand_stream(rng, 30, 200, 900)
+    T, P = rand_table(rng, m), rand_struct_pssm(rng, m)
+    motif = ctx.motif(T, P)
+    want_seq, want_st = oracle.stream_seq(s.codes, T), oracle.stream_struct(s.profile, P)
+    dev = torch.device("cuda:0")
+    n = s.n_pos
+    big = 96 << 20                                  # every array spans several 64 MB chunks (PFMSCAN_PLACE_CHUNK_MB below)
+    os.environ["PFMSCAN_PLACE_CHUNK_MB"] = "64"
+    try:
+        for cycle, plain in enumerate((False, True, False, False)):
+            arrs = ctx.place_alloc([big + n * 28, big + n * 8, big + n * 4, big + n], plain=plain)
+            note = ctx.place_note()
+            assert ("NOT tuned" in note) == plain, note
+            raw = [torch.as_tensor(a, device=dev) for a in arrs]
+            assert all(t.data_ptr() == a.ptr and t.numel() == a.nbytes for t, a in zip(raw, arrs))
+            pattern = [torch.randint(0, 255, (a.nbytes,), dtype=torch.uint8, device=dev) for a in arrs]
+            for t, p in zip(raw, pattern):
+                t.copy_(p)
+            torch.cuda.synchronize()
+            for t, p in zip(raw, pattern):
+                assert torch.equal(t, p), "cycle %d: a placed array does not hold what was written" % cycle
+            off = big                                # the scan's arrays at the END of the placed ranges: the last chunks are used too
+            raw[0][off:off + n * 28].copy_(torch.from_numpy(s.profile.view(np.uint8).reshape(-1)).to(dev))
+            raw[3][off:off + n].copy_(torch.from_numpy(s.codes).to(dev))
+            torch.cuda.synchronize()
+            ctx.scan_dev(motif, arrs[3].ptr + off, arrs[0].ptr + off, _lib.PROFILE_F32, n, arrs[2].ptr + off, arrs[1].ptr + off, None)
+            ctx.synchronize()
+            got_seq = raw[2][off:off + n * 4].view(torch.float32).cpu().numpy()
+            got_st = raw[1][off:off + n * 8].view(torch.float64).cpu().numpy()
+            assert_f32_bits_equal(got_seq, want_seq)
+            assert_struct_close(got_st, want_st)
+            del raw, pattern
+            ctx.place_free(arrs[0])
+        with pytest.raises(Exception):
+            ctx.place_free(arrs[0])                  # freed already
+        with pytest.raises(Exception):
+            ctx.place_alloc([0, 16])
+    finally:
+        del os.environ["PFMSCAN_PLACE_CHUNK_MB"]
     motif.close()

@@ -189,11 +189,13 @@ int main(int argc, char **argv)
     const double br = (double)n_pos * 29, bw = (double)n_pos * 12;
     std::printf("positions %lld: %.3f GB read + %.3f GB written = %.3f GB per pass (C3's launch moves 12.287 GB)\n", (long long)n_pos,
                 br * 1e-9, bw * 1e-9, (br + bw) * 1e-9);
-    if (g_quick) {                                              // the forms that were fastest on every box so far
-        run_copy<2048, 256, true>("copy  tile 2048, nt loads", a, br, bw);
-        run_lds<1024, 256>("lds-dma tile 1024 (29 KB)", a, br, bw);
-        run_lds<2048, 256>("lds-dma tile 2048 (58 KB)", a, br, bw);
-        run_lds<1024, 128>("lds-dma tile 1024, 128 threads", a, br, bw);
+    if (g_quick) {                                              // the forms that were fastest on every box so far, three rounds:
+        for (int round = 0; round < 3; ++round) {               // the same box gives 1.86 .. 2.04 ms from one minute to the next
+            run_copy<2048, 256, true>("copy  tile 2048, nt loads", a, br, bw);
+            run_lds<1024, 256>("lds-dma tile 1024 (29 KB)", a, br, bw);
+            run_lds<2048, 256>("lds-dma tile 2048 (58 KB)", a, br, bw);
+            run_lds<1024, 128>("lds-dma tile 1024, 128 threads", a, br, bw);
+        }
         std::printf("floor_ms %.4f tb_per_s %.3f bytes %.0f\n", g_best_rw, (br + bw) / g_best_rw * 1e-9, br + bw);
         return 0;
     }
