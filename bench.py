@@ -151,7 +151,7 @@ def pmc_entry(workload):
     return {}
 
 
-def live_mixed_floor(records, length):
+def live_mixed_floor(records, length, placed=False):
     """tools/hbm_mixed `quick` as a child process on the same GPU, right after the timed region: the fastest of its
     read+write forms is what THIS box's memory system gives the headline's byte mix (29 B in + 12 B out per position,
     nothing scored).  None when the tool is not built (rnascan_amd/build.py: build_floor_tool)."""
@@ -161,14 +161,15 @@ def live_mixed_floor(records, length):
     if not os.access(exe, os.X_OK) or os.environ.get("PFMSCAN_BENCH_NO_FLOOR") or profiled:     # no child processes under a profiler
         return None
     try:
-        out = subprocess.run([exe, str(records), str(length), "quick"], capture_output=True, text=True, timeout=120)
+        out = subprocess.run([exe, str(records), str(length), "quick"] + (["placed"] if placed else []), capture_output=True, text=True, timeout=120)
     except (OSError, subprocess.TimeoutExpired):
         return None
     for ln in out.stdout.splitlines():
         if ln.startswith("floor_ms "):
             f = ln.split()
             return {"ms": float(f[1]), "tb_per_s": float(f[3]), "bytes": float(f[5]),
-                    "source": "tools/hbm_mixed %d %d quick, run by this bench.py on the same GPU after the timed region" % (records, length),
+                    "source": "tools/hbm_mixed %d %d quick%s, run by this bench.py on the same GPU after the timed region" % (records, length, " placed" if placed else ""),
+                    "arrays": "pfmscan_place_alloc, like the bench's own" if placed else "hipMalloc, wherever the driver puts them",
                     "note": "fastest of 4 read+write forms (vector-load tiles, LDS-DMA tiles) in 3 rounds, each the median of 5 x 20 passes; "
                             "the figure moves by up to 10 % from one minute to the next on one box, like the kernel's own time"}
     return None
@@ -730,7 +731,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else "k_profile",
+                "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else (
+                    "k_profile_fixed" if (args.mode == "scores" and 9 <= args.width <= 18 and not os.environ.get("PFMSCAN_PROFILE_GENERIC")) else "k_profile"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
                 "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": alg_bytes,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
@@ -739,7 +741,7 @@ def main():
         if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32":
             # the same byte mix (29 B in + 12 B out per position) moved by a program that scores nothing
             # (tools/hbm_mixed.hip, measured on this chip in round 4): what the memory system gives this access pattern
-            live = live_mixed_floor(args.records, args.length) if (rank == 0 and world == 1) else None
+            live = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned") if (rank == 0 and world == 1) else None
             floor = pmc_entry("c3_mixed_floor")
             if live is not None:
                 result["roofline"]["mixed_read_write_floor"] = dict(live, frac_of_floor=live["ms"] / kernel_ms, kernel_over_floor=kernel_ms / live["ms"])

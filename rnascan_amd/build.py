@@ -74,7 +74,7 @@ def build_floor_tool(force=False):
     tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
     src, exe = os.path.join(tools, "hbm_mixed.hip"), os.path.join(tools, "hbm_mixed")
     if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
-        subprocess.check_call([hipcc_path(), "-O3", "--offload-arch=gfx950", src, "-o", exe])
+        subprocess.check_call([hipcc_path(), "-O3", "--offload-arch=gfx950", src, "-o", exe, "-ldl"])
     return exe
 
 

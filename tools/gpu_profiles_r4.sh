@@ -5,7 +5,7 @@ R=r4
 OUT=gpurun_out/$R
 mkdir -p $OUT
 ROOT=$(pwd)
-run() { name=$1; shift; echo "== $name: bench.py $*"; python3 bench.py "$@" 2>>$OUT/err.log | tail -1 > $OUT/$name.json; python3 -c "
+run() { name=$1; shift; echo "== $name: bench.py $*"; if [ "$name" = bench_c3_generic_kernel ]; then export PFMSCAN_PROFILE_GENERIC=1; else unset PFMSCAN_PROFILE_GENERIC; fi; python3 bench.py "$@" 2>>$OUT/err.log | tail -1 > $OUT/$name.json; python3 -c "
 import json,sys; d=json.load(open('$OUT/$name.json')); print('   ms_per_step %.4f value %.4g %s n_gpus %d' % (d['ms_per_step'], d['value'], d['unit'], d['n_gpus']))"; }
 run bench_c3_default
 run bench_c5_library --workload c5 --steps 10 --warmup 2 --no-cpu-baseline
@@ -20,6 +20,10 @@ run bench_c2_hits_none --workload c2 --width 8 --mode hits --minscore-seq 30 --n
 run bench_c2_w4_hits_m2 --workload c2 --width 4 --mode hits --minscore-seq 2 --no-cpu-baseline
 run bench_c4_shard_125k --records 125000 --no-cpu-baseline --no-secondary
 tools/hbm_mixed > $OUT/hbm_mixed_ceiling.txt 2>&1
+tools/hbm_mixed 100000 3000 placed > $OUT/hbm_mixed_ceiling_placed.txt 2>&1
+run bench_c3_torch_allocator --no-cpu-baseline --no-secondary --placement torch
+run bench_c3_generic_kernel --no-cpu-baseline --no-secondary
+unset PFMSCAN_PROFILE_GENERIC
 cd /tmp && export TMPDIR=/tmp
 export PFMSCAN_BENCH_NO_FLOOR=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_c3 -- python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 200 > $ROOT/$OUT/trace_c3.log 2>&1

@@ -10,13 +10,15 @@
 //   lds      the same with the tile staged through LDS by LDS-DMA (global_load_lds_dwordx4), as k_profile stages it
 //   read     inputs only            write    outputs only
 // swept over tile sizes and resident workgroups per CU.
-//   hipcc -O3 --offload-arch=gfx950 tools/hbm_mixed.hip -o tools/hbm_mixed && tools/hbm_mixed [records] [length] [quick]
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_mixed.hip -o tools/hbm_mixed && tools/hbm_mixed [records] [length] [quick] [placed]   (-ldl)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
@@ -174,14 +176,40 @@ static void run_lds(const char *name, Args a, double bytes_r, double bytes_w)
 int main(int argc, char **argv)
 {
     const int64_t records = argc > 1 ? std::atoll(argv[1]) : 100000, length = argc > 2 ? std::atoll(argv[2]) : 3000;
-    g_quick = argc > 3 && std::strcmp(argv[3], "quick") == 0;
+    for (int i = 3; i < argc; ++i) g_quick = g_quick || std::strcmp(argv[i], "quick") == 0;
     int64_t n_pos = records * (length + 1);
     n_pos -= n_pos % 8192;                                      // whole tiles for every tile size below
     Args a;
-    CHECK(hipMalloc((void **)&a.codes, (size_t)n_pos));
-    CHECK(hipMalloc((void **)&a.profile, (size_t)n_pos * 28));
-    CHECK(hipMalloc((void **)&a.out_seq, (size_t)n_pos * 4));
-    CHECK(hipMalloc((void **)&a.out_struct, (size_t)n_pos * 8));
+    bool placed = false;
+    for (int i = 3; i < argc; ++i) placed = placed || std::strcmp(argv[i], "placed") == 0;
+    if (placed) {
+        // the four arrays from the library's allocator (pfmscan_place_alloc: chunks of HBM that do not share DRAM banks), so that
+        // the floor is measured on arrays placed like bench.py's: libpfmscan.so is found next to this tool's directory
+        std::string self(argv[0]);
+        const size_t slash = self.rfind('/');
+        const std::string lib = (slash == std::string::npos ? std::string(".") : self.substr(0, slash)) + "/../rnascan_amd/libpfmscan.so";
+        void *h = dlopen(lib.c_str(), RTLD_NOW);
+        if (!h) { std::fprintf(stderr, "%s\n", dlerror()); return 1; }
+        auto ctx_create = (int (*)(int, void **))dlsym(h, "pfmscan_ctx_create");
+        auto place = (int (*)(void *, int, const int64_t *, void **, int))dlsym(h, "pfmscan_place_alloc");
+        auto note = (const char *(*)(const void *))dlsym(h, "pfmscan_place_note");
+        auto last = (const char *(*)(const void *))dlsym(h, "pfmscan_last_error");
+        void *ctx = nullptr;
+        if (!ctx_create || !place || ctx_create(0, &ctx) != 0) { std::fprintf(stderr, "libpfmscan: no context\n"); return 1; }
+        const int64_t bytes[4] = {n_pos * 28, n_pos * 8, n_pos * 4, n_pos};
+        void *p[4];
+        if (place(ctx, 4, bytes, p, 0) != 0) { std::fprintf(stderr, "pfmscan_place_alloc: %s\n", last(ctx)); return 1; }
+        a.profile = (const unsigned char *)p[0];
+        a.out_struct = (double *)p[1];
+        a.out_seq = (float *)p[2];
+        a.codes = (const unsigned char *)p[3];
+        std::printf("placed: %s\n", note(ctx));
+    } else {
+        CHECK(hipMalloc((void **)&a.codes, (size_t)n_pos));
+        CHECK(hipMalloc((void **)&a.profile, (size_t)n_pos * 28));
+        CHECK(hipMalloc((void **)&a.out_seq, (size_t)n_pos * 4));
+        CHECK(hipMalloc((void **)&a.out_struct, (size_t)n_pos * 8));
+    }
     CHECK(hipMemset((void *)a.codes, 1, (size_t)n_pos));
     CHECK(hipMemset((void *)a.profile, 0, (size_t)n_pos * 28));
     a.n_pos = n_pos;
