@@ -94,9 +94,17 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
     for (int r = 0; r < n_arrays; ++r)
         if (bytes[r] <= 0) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_place_alloc: array sizes must be positive");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool plain = (flags & PFMSCAN_PLACE_PLAIN) || std::getenv("PFMSCAN_PLACE_PLAIN");
+    bool plain = (flags & PFMSCAN_PLACE_PLAIN) || std::getenv("PFMSCAN_PLACE_PLAIN");
     size_t chunk = (size_t)2048 << 20;
-    if (const char *v = std::getenv("PFMSCAN_PLACE_CHUNK_MB")) chunk = (size_t)std::max(64, std::min(16384, std::atoi(v))) << 20;
+    int64_t largest = 0;
+    for (int r = 0; r < n_arrays; ++r) largest = std::max(largest, bytes[r]);
+    if (const char *v = std::getenv("PFMSCAN_PLACE_CHUNK_MB")) {
+        chunk = (size_t)std::max(64, std::min(16384, std::atoi(v))) << 20;
+    } else {
+        // small sets: smaller chunks, and below 512 MB no measurement (such a scan is over before its streams can disturb each other)
+        while (chunk > ((size_t)64 << 20) && (size_t)largest <= chunk / 2) chunk /= 2;
+        if (chunk < ((size_t)512 << 20)) plain = true;
+    }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -171,9 +179,12 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
             // pairwise disturbance of the empty chunks: two write streams of `each` bytes, the faster of two launches
             const size_t each = chunk;          // whole chunks: a chunk may straddle two bank regions, its first part says nothing about its end
             std::vector<double> L((size_t)n * n, 0.0);
-            hipEvent_t e0, e1;
-            HIP_TRY(ctx, hipEventCreate(&e0));
-            HIP_TRY(ctx, hipEventCreate(&e1));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                drop_all();
+                return fail(ctx, PFMSCAN_E_HIP, "pfmscan_place_alloc: hipEventCreate failed");
+            }
             const unsigned grid = (unsigned)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 16;
             hipLaunchKernelGGL(k_place_probe, dim3(grid), dim3(BLOCK), 0, ctx->stream, (u32x4 *)window, (u32x4 *)(window + chunk), each / 16);   // warm
             for (int i = 0; i < n; ++i)
