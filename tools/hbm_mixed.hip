@@ -34,6 +34,7 @@ struct Args {
     double *out_struct;              // [n_pos]
     int64_t n_pos;
     int do_read, do_write;
+    int fronts;                      // k_lds: workgroup b takes tile b / F of part b % F (the stream walked at F places at once)
 };
 
 // one workgroup = one tile of TILE positions; every thread moves 16 bytes per access
@@ -78,7 +79,12 @@ template <int TILE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_lds(const Args a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    int64_t tile = blockIdx.x;
+    if (a.fronts > 1) {
+        const int64_t per = (int64_t)gridDim.x / a.fronts;
+        tile = (int64_t)(blockIdx.x % (unsigned)a.fronts) * per + blockIdx.x / (unsigned)a.fronts;
+    }
+    const int64_t tile0 = tile * TILE;
     if (tile0 + TILE > a.n_pos) return;
     constexpr int PB = TILE * 28, CB = TILE;                   // both multiples of 1024 for the tiles used here
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -155,9 +161,10 @@ static void run_copy(const char *name, Args a, double bytes_r, double bytes_w, u
 }
 
 template <int TILE, int BLOCK>
-static void run_lds(const char *name, Args a, double bytes_r, double bytes_w)
+static void run_lds(const char *name, Args a, double bytes_r, double bytes_w, int fronts = 1)
 {
-    const unsigned grid = (unsigned)(a.n_pos / TILE);
+    const unsigned grid = (unsigned)(a.n_pos / TILE / fronts * fronts);
+    a.fronts = fronts;
     const int lds = TILE * 29;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds<TILE, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     struct { const char *what; int r, w; } modes[] = {{"read+write", 1, 1}, {"read only", 1, 0}};
@@ -214,6 +221,7 @@ int main(int argc, char **argv)
     CHECK(hipMemset((void *)a.profile, 0, (size_t)n_pos * 28));
     a.n_pos = n_pos;
     a.do_read = a.do_write = 1;
+    a.fronts = 1;
     const double br = (double)n_pos * 29, bw = (double)n_pos * 12;
     std::printf("positions %lld: %.3f GB read + %.3f GB written = %.3f GB per pass (C3's launch moves 12.287 GB)\n", (long long)n_pos,
                 br * 1e-9, bw * 1e-9, (br + bw) * 1e-9);
@@ -240,6 +248,10 @@ int main(int argc, char **argv)
     run_lds<1024, 256>("lds-dma tile 1024 (29 KB)", a, br, bw);
     run_lds<2048, 256>("lds-dma tile 2048 (58 KB)", a, br, bw);
     run_lds<1024, 128>("lds-dma tile 1024, 128 threads", a, br, bw);
+    run_lds<2048, 256>("lds-dma tile 2048, 2 fronts", a, br, bw, 2);
+    run_lds<2048, 256>("lds-dma tile 2048, 4 fronts", a, br, bw, 4);
+    run_lds<2048, 256>("lds-dma tile 2048, 8 fronts", a, br, bw, 8);
+    run_lds<2048, 256>("lds-dma tile 2048, 16 fronts", a, br, bw, 16);
     const double best_hint = (br + bw) / 8e12 * 1e3;
     std::printf("at the 8 TB/s spec peak the pass would take %.3f ms\n", best_hint);
     std::printf("floor_ms %.4f tb_per_s %.3f bytes %.0f\n", g_best_rw, (br + bw) / g_best_rw * 1e-9, br + bw);
