@@ -96,6 +96,7 @@ int pfmscan_ctx_create(int device, pfmscan_ctx **out)
     if (const char *v = std::getenv("PFMSCAN_DMA")) ctx->tune.dma = std::atoi(v) != 0;
     if (const char *v = std::getenv("PFMSCAN_ABLATE")) ctx->tune.ablate = std::atoi(v);
     if (const char *v = std::getenv("PFMSCAN_PRIO")) ctx->tune.prio = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PFMSCAN_DMA_TAIL")) ctx->tune.dma_whole = std::atoi(v) == 0;
     if (const char *v = std::getenv("PFMSCAN_TWO_PHASE")) ctx->tune.two_phase = std::atoi(v) != 0;
     if (const char *v = std::getenv("PFMSCAN_TILES_PER_BLOCK")) ctx->tune.tiles_per_block = std::max(0, std::min(1024, std::atoi(v)));
     if (const char *v = std::getenv("PFMSCAN_PREFILTER")) ctx->tune.prefilter = std::atoi(v) != 0;
@@ -286,6 +287,7 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.struct_finite = mo->struct_finite;
     a.ablate = ctx->tune.ablate;
     a.prio = ctx->tune.prio;
+    a.dma_whole = ctx->tune.dma_whole;
     return PFMSCAN_OK;
 }
 

@@ -66,6 +66,7 @@ struct ScanArgs {
     int hit_shards;                  // 1 (public _dev contract) or a power of two: workgroup b appends to shard
                                      // b & (hit_shards-1), i.e. to slots [shard*capacity, (shard+1)*capacity)
     int prio;                    // k_profile: staging instructions at raised wave priority (Tuning::prio)
+    int dma_whole;               // k_profile: the last LDS-DMA piece of a region in full (Tuning::dma_whole; default: only the lanes with needed bytes)
     int ablate;                  // timing diagnostics (PFMSCAN_ABLATE): 1 no scoring, 2 no staging, 4 no output
     int64_t pos_offset;          // added to every reported hit position (chunked host pipeline: position of the chunk in the stream)
 };
@@ -80,6 +81,7 @@ struct Tuning {
     int dma = 1;            // k_profile: stage the tile with LDS-DMA (global_load_lds, 2.34 ms on C3) instead of
                             // through registers (2.51 ms)
     int prio = 1;           // k_profile: s_setprio 3 while a new workgroup issues its tile's loads (PFMSCAN_PRIO=0: off)
+    int dma_whole = 0;      // PFMSCAN_DMA_TAIL=0: 1
     int ablate = 0;         // see ScanArgs::ablate; results are WRONG when non-zero
     int prefilter = 1;      // hits over 4-letter alphabets: fp32 two-letter prefilter, exact fp64 re-score of survivors
     int tiles_per_block = 0; // k_letters_pre: 0 = pick from the stream length; > 0 forces it (PFMSCAN_TILES_PER_BLOCK, tests)

@@ -85,13 +85,19 @@ __device__ __forceinline__ void stage_tile(const ScanArgs &a, int64_t tile0, uns
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
             const int npiece = prof_bytes >> 10;
             const uint32_t base = lds_addr(buf);
+            // only the lanes whose 16 bytes hold rows / letters the tile reads take part in the LAST piece of each region: the
+            // pieces are whole KiB of LDS, the tile needs (TILE + m) rows = 36 176 of 36 864 B and TILE + m of 2 048 code bytes at
+            // w = 12 -- 1.4 KB per tile that the neighbouring tile (on another XCD) requests again (PFMSCAN_DMA_TAIL=0: whole pieces)
+            const int pneed = a.dma_whole ? prof_bytes : (L::TILE + m) * 7 * (int)sizeof(PROF_T);
+            const int cneed = a.dma_whole ? code_bytes : L::TILE + m;
             for (int pc = wave; pc < npiece; pc += BLOCK / 64)
-                dma_issue16(gsrc + ((size_t)pc << 10) + (lane << 4), base + ((uint32_t)pc << 10));
+                if ((pc << 10) + (lane << 4) < pneed) dma_issue16(gsrc + ((size_t)pc << 10) + (lane << 4), base + ((uint32_t)pc << 10));
             if (HAS_SEQ) {
                 const unsigned char *csrc = a.codes + tile0;
                 const int ncp = code_bytes >> 10;
                 for (int pc = wave; pc < ncp; pc += BLOCK / 64)
-                    dma_issue16(csrc + ((size_t)pc << 10) + (lane << 4), base + (uint32_t)prof_bytes + ((uint32_t)pc << 10));
+                    if ((pc << 10) + (lane << 4) < cneed)
+                        dma_issue16(csrc + ((size_t)pc << 10) + (lane << 4), base + (uint32_t)prof_bytes + ((uint32_t)pc << 10));
             }
         } else {
             // register staging, 4 x 16 B per thread in flight per round (measured faster
