@@ -90,13 +90,14 @@ __device__ __forceinline__ void stage_tile(const ScanArgs &a, int64_t tile0, uns
             // w = 12 -- 1.4 KB per tile that the neighbouring tile (on another XCD) requests again (PFMSCAN_DMA_TAIL=0: whole pieces)
             const int pneed = a.dma_whole ? prof_bytes : (L::TILE + m) * 7 * (int)sizeof(PROF_T);
             const int cneed = a.dma_whole ? code_bytes : L::TILE + m;
-            for (int pc = wave; pc < npiece; pc += BLOCK / 64)
-                if ((pc << 10) + (lane << 4) < pneed) dma_issue16(gsrc + ((size_t)pc << 10) + (lane << 4), base + ((uint32_t)pc << 10));
+            for (int pc = wave; pc < npiece; pc += BLOCK / 64)      // pc is wave-uniform: only a region's last piece pays the lane test
+                if (pc + 1 < npiece || (pc << 10) + (lane << 4) < pneed)
+                    dma_issue16(gsrc + ((size_t)pc << 10) + (lane << 4), base + ((uint32_t)pc << 10));
             if (HAS_SEQ) {
                 const unsigned char *csrc = a.codes + tile0;
                 const int ncp = code_bytes >> 10;
                 for (int pc = wave; pc < ncp; pc += BLOCK / 64)
-                    if ((pc << 10) + (lane << 4) < cneed)
+                    if (pc + 1 < ncp || (pc << 10) + (lane << 4) < cneed)
                         dma_issue16(csrc + ((size_t)pc << 10) + (lane << 4), base + (uint32_t)prof_bytes + ((uint32_t)pc << 10));
             }
         } else {
