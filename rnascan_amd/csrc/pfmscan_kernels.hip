@@ -112,15 +112,33 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
         // one guarded group per motif position: a guard, not a break (a constant trip count is what
         // lets hipcc unroll this), and no wider groups (2 or 4 positions per guard keep more look-ups
         // in flight but cost 2-3 waves of occupancy: 15-50 % slower at every width)
+        if constexpr (NDW == 5) {
+            // PFMs up to 16 wide: the table offset of every position the round touches is extracted ONCE (W + 15 values) instead
+            // of once per (row, window) -- the same byte serves up to W windows at W different rows; the rows are immediate
+            // offsets of the ds_read (C2 at w = 8 / 16: 0.278 -> 0.273 / 0.413 -> 0.404 ms, four interleaved pairs).  Wider
+            // buckets would hold 39 / 71 such registers and lose the occupancy they live on.
+            uint32_t adr[W + (NDW - 1) * 4 - 1];
 #pragma unroll
-        for (int j = 0; j < (NDW - 1) * 4; ++j) {
-            if (j < m) {
-                const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+            for (int q = 0; q < W + (NDW - 1) * 4 - 1; ++q) adr[q] = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
 #pragma unroll
-                for (int v = 0; v < W; ++v) {
-                    const int q = j + v;    // byte index relative to p0, compile-time
-                    const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
-                    acc[v] += *reinterpret_cast<const double *>(row + b);
+            for (int j = 0; j < (NDW - 1) * 4; ++j) {
+                if (j < m) {
+                    const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+#pragma unroll
+                    for (int v = 0; v < W; ++v) acc[v] += *reinterpret_cast<const double *>(row + adr[j + v]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < (NDW - 1) * 4; ++j) {
+                if (j < m) {
+                    const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+#pragma unroll
+                    for (int v = 0; v < W; ++v) {
+                        const int q = j + v;    // byte index relative to p0, compile-time
+                        const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+                        acc[v] += *reinterpret_cast<const double *>(row + b);
+                    }
                 }
             }
         }
