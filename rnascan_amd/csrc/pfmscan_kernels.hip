@@ -982,66 +982,6 @@ __device__ __forceinline__ void compute_tile(const PROF_T *prof_lds, const unsig
     }
 }
 
-// outputs of one tile: hits, or LDS transpose + 16-byte coalesced stores.
-// `stage` may alias the tile buffer (callers barrier before and after).
-template <int V, bool HAS_SEQ, bool HITS>
-__device__ __forceinline__ void emit_tile(const ScanArgs &a, int64_t tile0, int la, double (&acc_st)[V], double (&acc_sq)[V],
-                                          unsigned char *stage)
-{
-    constexpr int TILE = V * BLOCK;
-    const int tid = threadIdx.x;
-    const int64_t n_pos = a.n_pos;
-    if (tile0 + TILE + a.m > n_pos) {               // workgroup-uniform: only the last tile(s) of the stream
-        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-            if (tile0 + la + v + a.m > n_pos) acc_st[v] = qnan;   // window runs past the stream end
-    }
-    if (HITS) {
-        uint32_t mask = 0;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            bool pass = (tile0 + la + v < n_pos) && (acc_st[v] > a.thr_struct);
-            if (HAS_SEQ) pass = pass && ((double)(float)acc_sq[v] > a.thr_seq);
-            if (pass) mask |= 1u << v;
-        }
-        emit_hits_block<V>(
-            mask, [&](int i) { return tile0 + la + i; }, [&](int i) { return (float)acc_sq[i]; },
-            [&](int i) { return acc_st[i]; }, a);
-        return;
-    }
-    __syncthreads();                               // every wave is done with the tile
-    float *so = reinterpret_cast<float *>(stage);
-    double *sto = reinterpret_cast<double *>(stage + TILE * 4);
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-        if (HAS_SEQ) so[la + v] = (float)acc_sq[v];
-        sto[la + v] = acc_st[v];
-    }
-    __syncthreads();
-    if (HAS_SEQ && a.out_seq) {
-        for (int c = tid; c < TILE / 4; c += BLOCK) {
-            const int64_t p = tile0 + 4 * (int64_t)c;
-            if (p + 4 <= n_pos) {
-                __builtin_nontemporal_store(reinterpret_cast<const f32x4 *>(so)[c], reinterpret_cast<f32x4 *>(a.out_seq + p));
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (p + e < n_pos) a.out_seq[p + e] = so[4 * c + e];
-            }
-        }
-    }
-    if (a.out_struct) {
-        for (int c = tid; c < TILE / 2; c += BLOCK) {
-            const int64_t p = tile0 + 2 * (int64_t)c;
-            if (p + 2 <= n_pos) {
-                __builtin_nontemporal_store(reinterpret_cast<const f64x2 *>(sto)[c], reinterpret_cast<f64x2 *>(a.out_struct + p));
-            } else if (p < n_pos) {
-                a.out_struct[p] = sto[2 * c];
-            }
-        }
-    }
-}
-
 // one tile per workgroup; overlap comes from several resident workgroups per CU
 // launch bound = the residency the LDS tile allows (4 workgroups/CU at V=5, 3 at V=7)
 template <int V, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS, int DMA>

@@ -113,7 +113,7 @@ __device__ __forceinline__ void compute_tile_fixed(const PROF_T *prof_lds, const
     }
 }
 
-template <int V, int MW, bool HAS_SEQ, typename PROF_T, bool FINITE>
+template <int V, int MW, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
 __global__ __launch_bounds__(BLOCK, 4) void k_profile_fixed(const ScanArgs a)
 {
     using L = ProfileLayout<V, PROF_T>;
@@ -132,17 +132,20 @@ __global__ __launch_bounds__(BLOCK, 4) void k_profile_fixed(const ScanArgs a)
     double acc_st[V], acc_sq[V];
     compute_tile_fixed<V, MW, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(smem), smem + prof_bytes, tseq_lds, a.struct_pssm,
                                                        la, acc_st, acc_sq);
-    emit_tile_wave<V, HAS_SEQ, PROF_T>(a, tile0, la, acc_st, acc_sq, smem, MW);
+    if (HITS)
+        emit_tile<V, HAS_SEQ, true>(a, tile0, la, acc_st, acc_sq, smem);      // the fused combined filter: seq > thr && struct > thr
+    else
+        emit_tile_wave<V, HAS_SEQ, PROF_T>(a, tile0, la, acc_st, acc_sq, smem, MW);
 }
 
-template <int MW, bool HAS_SEQ, typename PROF_T, bool FINITE>
+template <int MW, bool HAS_SEQ, typename PROF_T, bool FINITE, bool HITS>
 static hipError_t launch_fixed_inst(const ScanArgs &a, hipStream_t stream)
 {
     constexpr int V = 5;       // 7 windows per thread (1792-position tiles, 162 VGPRs, 3 workgroups per CU): 2.14-2.16 ms on C3 beside 2.07-2.15
     using L = ProfileLayout<V, PROF_T>;
     const unsigned grid = (unsigned)((a.n_pos + L::TILE - 1) / L::TILE);
     const int lds = L::total(MW, HAS_SEQ, 1);
-    auto kern = k_profile_fixed<V, MW, HAS_SEQ, PROF_T, FINITE>;
+    auto kern = k_profile_fixed<V, MW, HAS_SEQ, PROF_T, FINITE, HITS>;
     static std::atomic<uint64_t> configured{0};     // per instantiation, one bit per device
     hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kern), configured);
     if (e != hipSuccess) return e;
@@ -150,23 +153,24 @@ static hipError_t launch_fixed_inst(const ScanArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int MW>
+template <int MW, bool HITS>
 static hipError_t launch_fixed_width(const ScanArgs &a, hipStream_t stream)
 {
     const bool has_seq = a.letter_table != nullptr, fin = a.struct_finite != 0;
     if (a.profile_dtype == PFMSCAN_PROFILE_F64) {
-        if (has_seq) return fin ? launch_fixed_inst<MW, true, double, true>(a, stream) : launch_fixed_inst<MW, true, double, false>(a, stream);
-        return fin ? launch_fixed_inst<MW, false, double, true>(a, stream) : launch_fixed_inst<MW, false, double, false>(a, stream);
+        if (has_seq) return fin ? launch_fixed_inst<MW, true, double, true, HITS>(a, stream) : launch_fixed_inst<MW, true, double, false, HITS>(a, stream);
+        return fin ? launch_fixed_inst<MW, false, double, true, HITS>(a, stream) : launch_fixed_inst<MW, false, double, false, HITS>(a, stream);
     }
-    if (has_seq) return fin ? launch_fixed_inst<MW, true, float, true>(a, stream) : launch_fixed_inst<MW, true, float, false>(a, stream);
-    return fin ? launch_fixed_inst<MW, false, float, true>(a, stream) : launch_fixed_inst<MW, false, float, false>(a, stream);
+    if (has_seq) return fin ? launch_fixed_inst<MW, true, float, true, HITS>(a, stream) : launch_fixed_inst<MW, true, float, false, HITS>(a, stream);
+    return fin ? launch_fixed_inst<MW, false, float, true, HITS>(a, stream) : launch_fixed_inst<MW, false, float, false, HITS>(a, stream);
 }
 
-// true when a fixed-width instantiation took the all-scores scan (result in *err); false: the caller runs the generic kernel
+// true when a fixed-width instantiation took the scan (all scores, or the fused hits pass), result in *err; false: the caller
+// runs the generic kernel
 bool launch_profile_fixed(const ScanArgs &a, hipStream_t stream, hipError_t *err)
 {
     const bool off = std::getenv("PFMSCAN_PROFILE_GENERIC") != nullptr;      // tests and A/B runs: the width-generic kernel
-    if (off || a.hits || a.ablate || !a.struct_pssm || !a.profile || a.out_letters_f64) return false;
+    if (off || a.ablate || !a.struct_pssm || !a.profile || a.out_letters_f64) return false;
     // C3 with placed arrays, generic / fixed in ms (tools/ab_fixed.sh, three interleaved pairs each, profiles/r4/NOTES.md):
     // w = 6: 2.00 / 1.99, 8: 1.960 / 1.974, 9: 1.990 / 1.976, 10: 2.038 / 1.966, 11: 2.107 / 1.993, 12: 2.188 / 2.052,
     // 16: 2.538 / 2.328, 18: 2.707 / 2.475 -- below nine rows the generic loop's two full rounds of five cost nothing extra
@@ -174,7 +178,7 @@ bool launch_profile_fixed(const ScanArgs &a, hipStream_t stream, hipError_t *err
     if (const char *v = std::getenv("PFMSCAN_PROFILE_FIXED_MIN")) min_w = std::atoi(v);
     if (a.m < min_w) return false;
     switch (a.m) {
-#define FIXED_WIDTH(W) case W: *err = launch_fixed_width<W>(a, stream); return true;
+#define FIXED_WIDTH(W) case W: *err = a.hits ? launch_fixed_width<W, true>(a, stream) : launch_fixed_width<W, false>(a, stream); return true;
     FIXED_WIDTH(4) FIXED_WIDTH(5) FIXED_WIDTH(6) FIXED_WIDTH(7) FIXED_WIDTH(8) FIXED_WIDTH(9) FIXED_WIDTH(10) FIXED_WIDTH(11)
     FIXED_WIDTH(12) FIXED_WIDTH(13) FIXED_WIDTH(14) FIXED_WIDTH(15) FIXED_WIDTH(16) FIXED_WIDTH(17) FIXED_WIDTH(18)
 #undef FIXED_WIDTH

@@ -566,7 +566,21 @@ def test_fixed_width_profile_kernel_equals_the_generic_one(ctx, oracle, monkeypa
     fixed_seq, fixed_st = ctx.scan_host(motif, codes, s.profile)
     monkeypatch.setenv("PFMSCAN_PROFILE_GENERIC", "1")
     gen_seq, gen_st = ctx.scan_host(motif, codes, s.profile)
+    # the fused hits pass of the same instantiation (seq > thr && struct > thr; half of the windows pass the letter threshold,
+    # so the combined scan takes the fused k_profile pass, not letters first): the same hits with the same score bits
+    fin = gen_st[np.isfinite(gen_st)]
+    thr_t = float(np.quantile(fin, 0.5)) if len(fin) else 0.0
+    thr_s = -np.inf
+    if has_seq:
+        fs = gen_seq[np.isfinite(gen_seq)].astype(np.float64)
+        thr_s = float(np.quantile(fs, 0.3)) if len(fs) else 0.0
+    gen_hits = ctx.hits_host(motif, codes, s.profile, thr_s, thr_t)
     monkeypatch.delenv("PFMSCAN_PROFILE_GENERIC")
+    fixed_hits = ctx.hits_host(motif, codes, s.profile, thr_s, thr_t)
+    assert (len(gen_hits[0]) > 20 or inf_frac > 0) and np.array_equal(fixed_hits[0], gen_hits[0])
+    assert np.array_equal(fixed_hits[2].view(np.uint64), gen_hits[2].view(np.uint64))
+    if has_seq:
+        assert np.array_equal(fixed_hits[1].view(np.uint32), gen_hits[1].view(np.uint32))
     motif.close()
     assert np.array_equal(fixed_st.view(np.uint64), gen_st.view(np.uint64))
     assert_struct_close(fixed_st, oracle.stream_struct(s.profile, P))
