@@ -732,7 +732,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else (
-                    "k_profile_fixed" if (args.mode == "scores" and 9 <= args.width <= 18 and not os.environ.get("PFMSCAN_PROFILE_GENERIC")) else "k_profile"),
+                    "k_profile_fixed" if (args.mode in ("scores", "hits") and 9 <= args.width <= 18 and not os.environ.get("PFMSCAN_PROFILE_GENERIC")) else "k_profile"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
                 "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": alg_bytes,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
