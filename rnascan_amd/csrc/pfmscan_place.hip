@@ -390,10 +390,14 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
     for (int r = 0; r < n_arrays; ++r) ptrs[r] = set->arrays[r].va;
     ctx->place_sets.push_back(set);
     char line[512];
-    std::snprintf(line, sizeof(line),
-                  "%d arrays in %d chunks of %zu MB; %s%d candidates in %d groups %zu GB apart, pair times %.4f .. %.4f ms; weighted disturbance of the "
-                  "chosen chunks %.3g, of the first chunks in driver order %.3g",
-                  n_arrays, total, chunk >> 20, tuned ? "" : "NOT tuned: ", n, groups, spacer >> 30, level_lo, level_hi, cost_chosen, cost_plain);
+    if (tuned)
+        std::snprintf(line, sizeof(line),
+                      "%d arrays in %d chunks of %zu MB; %d candidates in %d groups %zu GB apart, pair times %.4f .. %.4f ms; weighted disturbance of the "
+                      "chosen chunks %.3g, of the first chunks in driver order %.3g",
+                      n_arrays, total, chunk >> 20, n, groups, spacer >> 30, level_lo, level_hi, cost_chosen, cost_plain);
+    else
+        std::snprintf(line, sizeof(line), "%d arrays in %d chunks of %zu MB; NOT tuned: chunks in driver order%s", n_arrays, total, chunk >> 20,
+                      plain ? "" : " (no spare chunks to choose from)");
     ctx->place_note = std::string(line) + (note.empty() ? "" : "; " + note);
     return PFMSCAN_OK;
 }
