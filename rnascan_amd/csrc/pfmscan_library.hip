@@ -260,9 +260,13 @@ template <int K, int NG, int NP>
 __device__ __forceinline__ uint32_t lib_groupmask(const lds_cptr (&rowp)[NP], const int ng_real)
 {
     uint32_t gm = 0u;
+    int ngr = __builtin_amdgcn_readfirstlane(ng_real);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g < ng_real) {                              // scalar compare + branch; always taken for full passes
+        // (opaque: or hipcc turns the NG compares into NG lane masks computed before the chunk loop, spills them into VGPR lanes
+        // and pays two v_readlane per group to get them back)
+        asm volatile("" : "+s"(ngr));
+        if (g < ngr) {                                  // scalar compare + branch; always taken for full passes
             const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
             const bool flag = ((acc.x | acc.y | acc.z | acc.w) & 0x20080200u) != 0u;
             gm |= flag ? (1u << g) : 0u;
@@ -572,6 +576,15 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             const bool dead = (badbits != 0) || (rel0 + lane >= a.span);
             if (!__ballot(!dead)) continue;                  // nothing scorable in this chunk (wave-uniform)
             if (dead) rowp[0] = pairs_lds + pair_bytes;
+            // The row addresses as opaque registers: left alone hipcc keeps only the lane part ((pair code) << 4) and re-adds
+            // the LDS base of the tables at EVERY group's look-ups (four v_add_u32 per group of 23 VALU instructions in all);
+            // as finished addresses the group offset g * 256 is the immediate of the ds_read_b128.
+#pragma unroll
+            for (int t = 0; t < NP; ++t) {
+                uint32_t x = (uint32_t)(uintptr_t)rowp[t];
+                asm volatile("" : "+v"(x));
+                rowp[t] = (lds_cptr)(uintptr_t)x;
+            }
 
             const uint32_t relpos = (uint32_t)(rel0 + lane);
             if constexpr (MPG == 12) {
