@@ -610,13 +610,14 @@ def test_placed_arrays_hold_what_is_written_and_scan_like_any_other(ctx, oracle)
     os.environ["PFMSCAN_PLACE_CHUNK_MB"] = "64"
     try:
         for cycle, plain in enumerate((False, True, False, False)):
+            roomy = torch.cuda.mem_get_info()[0] > (110 << 30)       # the second attempt holds 48 GB and wants 96 GB spare
             if cycle == 3:
                 os.environ["PFMSCAN_PLACE_FORCE_RETRY"] = "1"      # the path taken when no pair of candidates is independent
             arrs = ctx.place_alloc([big + n * 28, big + n * 8, big + n * 4, big + n], plain=plain)
             os.environ.pop("PFMSCAN_PLACE_FORCE_RETRY", None)
             note = ctx.place_note()
             assert ("NOT tuned" in note) == plain, note
-            assert ("second attempt" in note) == (cycle == 3), note
+            assert ("second attempt" in note) == (cycle == 3 and roomy), note
             raw = [torch.as_tensor(a, device=dev) for a in arrs]
             assert all(t.data_ptr() == a.ptr and t.numel() == a.nbytes for t, a in zip(raw, arrs))
             pattern = [torch.randint(0, 255, (a.nbytes,), dtype=torch.uint8, device=dev) for a in arrs]
