@@ -187,6 +187,7 @@ struct LibArgs {
     const double *letters;                // [m * 4][nmp] fp64, transposed
     const double *pssm;                   // [m * 4][nmp][2] fp64: row j, column pair c/2, motif, c&1 (column 7 = 0); null = no structure side
     const double *thr_seq, *thr_struct;   // [nmp]
+    int struct_finite;                    // every cell of every structure PSSM of the library is finite: phase B chains the row FMAs
     int m, npair, nmp, ng, motif_base;
     int sort_batches;                     // A/B: phase B sorts each 64-item batch by motif group (PFMSCAN_LIB_SORT=1)
     int ng_real;                          // motif groups of the pass that hold motifs (<= ng, the layout of its tables): the rest is skipped

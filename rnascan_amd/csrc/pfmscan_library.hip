@@ -68,7 +68,10 @@ __device__ __forceinline__ uint32_t lib_codes4(const uint8_t *__restrict__ codes
 // spread over the banks; NMP is a compile-time constant, so the cell offsets are immediates.
 // Two blocks (2 x 28 VGPRs, either precision) are in flight and the values are used from the vectors they arrived in:
 // the double variant used to hold two 4-row blocks = 112 VGPRs + an unpacked copy and spilled 144 bytes per lane.
-template <typename PROF_T, int NMP>
+// FIN: every PSSM cell of the library is finite -> the 7 FMAs of a row go straight into the window sum (nan_to_num is the
+// identity on finite row-dots; k_profile's FINITE variant does the same, same terms in the same order), and a sum that came out
+// non-finite (NaN / inf in the PROFILE, or overflow) is recomputed by the per-row form.
+template <typename PROF_T, int NMP, bool FIN>
 __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t p, int m, const double *pssm_lds, int mo)
 {
     constexpr int RB = 16 / (int)sizeof(PROF_T);       // rows per block = elements per vector: 4 (float) or 2 (double)
@@ -88,14 +91,24 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
     auto row_dot = [&](int j, double v0, double v1, double v2, double v3, double v4, double v5, double v6) {
         const f64x2 *Pj = P + (size_t)j * 4 * NMP;
         const f64x2 p01 = Pj[0], p23 = Pj[NMP], p45 = Pj[2 * NMP], p67 = Pj[3 * NMP];
-        double d = v0 * p01.x;
-        d = fma(v1, p01.y, d);
-        d = fma(v2, p23.x, d);
-        d = fma(v3, p23.y, d);
-        d = fma(v4, p45.x, d);
-        d = fma(v5, p45.y, d);
-        d = fma(v6, p67.x, d);
-        score += lib_nan_to_num(d);
+        if (FIN) {
+            score = fma(v0, p01.x, score);
+            score = fma(v1, p01.y, score);
+            score = fma(v2, p23.x, score);
+            score = fma(v3, p23.y, score);
+            score = fma(v4, p45.x, score);
+            score = fma(v5, p45.y, score);
+            score = fma(v6, p67.x, score);
+        } else {
+            double d = v0 * p01.x;
+            d = fma(v1, p01.y, d);
+            d = fma(v2, p23.x, d);
+            d = fma(v3, p23.y, d);
+            d = fma(v4, p45.x, d);
+            d = fma(v5, p45.y, d);
+            d = fma(v6, p67.x, d);
+            score += lib_nan_to_num(d);
+        }
     };
     // element e (0 .. 7 RB - 1) of a block = row e / 7, column e % 7; it sits in q[e / RB][e % RB]
     auto rows = [&](int j0, const vec_t (&q)[7]) {
@@ -490,10 +503,16 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
             if (__builtin_amdgcn_ballot_w64(ok)) {
                 if (ok) {
 #ifdef LIB_DIAG_WRAP                                     // timing diagnostic only: the rows come from the first 2^20 positions (cache-resident): WRONG scores
-                    st = lib_struct_score<PROF_T, NMP>(a.profile, p & 0xFFFFF, m, pssm, mo);
+                    const int64_t ps = p & 0xFFFFF;
 #else
-                    st = lib_struct_score<PROF_T, NMP>(a.profile, p, m, pssm, mo);
+                    const int64_t ps = p;
 #endif
+                    bool exact = !a.struct_finite;                       // wave-uniform
+                    if (a.struct_finite) {
+                        st = lib_struct_score<PROF_T, NMP, true>(a.profile, ps, m, pssm, mo);
+                        exact = !(fabs(st) <= DBL_MAX);                  // NaN / inf in the profile, or overflow: the per-row form decides
+                    }
+                    if (exact) st = lib_struct_score<PROF_T, NMP, false>(a.profile, ps, m, pssm, mo);
                     ok = st > thr_t[mo];
                 }
             }

@@ -126,6 +126,7 @@ struct pfmscan_library {
     bool has_letters = true;           // false: structure-only library (k_profile_lib, pfmscan_proflib.hip): one pass, no letter tables
     double *d_pssm_rows = nullptr;     // structure-only: [n][m][7] fp64 as handed in
     int32_t *d_finite = nullptr;       // structure-only: [n] 1 = every cell of the motif's PSSM is finite
+    bool all_finite = false;           // seq + struct libraries: every cell of every structure PSSM is finite
     std::vector<double> pairsum;       // [n][npair][16] exact two-letter sums, index c0 | c1 << 2
     std::vector<LibPass> passes;
     uint16_t *d_pairs = nullptr;
@@ -191,6 +192,10 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
     lib->npair = (m + 1) / 2;
     lib->np_bucket = lib_np_bucket(m);
     lib->has_struct = struct_pssms != nullptr;
+    if (struct_pssms && !std::getenv("PFMSCAN_FORCE_GENERIC")) {
+        lib->all_finite = true;
+        for (size_t i = 0; i < (size_t)n_motifs * m * 7 && lib->all_finite; ++i) lib->all_finite = std::isfinite(struct_pssms[i]);
+    }
     const int npair = lib->npair;
     lib->pairsum.resize((size_t)n_motifs * npair * 16);
     for (int k = 0; k < n_motifs; ++k) pair_sums(letter_tables + (size_t)k * m * 8, m, lib->pairsum.data() + (size_t)k * npair * 16);
@@ -475,6 +480,7 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
             a.pssm = lib->has_struct ? lib->d_pssm + ps.pssm_off : nullptr;
             a.thr_seq = lib->d_thr + ps.thr_off;
             a.thr_struct = lib->d_thr + ps.thr_off + ps.nmp;
+            a.struct_finite = lib->all_finite ? 1 : 0;
             a.m = lib->m;
             a.npair = lib->npair;
             a.nmp = ps.nmp;
