@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
     // would be 64 bytes, 8 of them = the banks TWICE (codes c and c + 4 on the same banks: 2-way conflicts, measured +50 % at
     // w = 18 against w = 16) -- stride 80 puts the 16-byte pieces of the 8 codes on 8 different bank quads again
     constexpr int ESTR = NJ <= 2 ? 8 : (NJ <= 4 ? 16 : (NJ <= 8 ? 32 : 80));
-    constexpr int PSH = NJ <= 2 ? 3 : 4;               // the codes are pre-shifted inside their bytes: byte = code * 8 or code * 16
+    constexpr int PSH = NJ <= 2 ? 3 : (NJ <= 4 ? 4 : (NJ <= 8 ? 5 : 4));      // the codes are pre-shifted inside their bytes: byte = code * 8, * 16 or * 32 (7 * 32 still fits)
     constexpr int EDW = ESTR / 4;                      // dwords per entry
     constexpr int TROWS = 2 * NJ;                      // rows of the exact letter table (rows m .. are zeros)
     constexpr int NRAW = (2 * NJ + 3) / 4 + 1;         // aligned code dwords that hold a window's 2 NJ letters at any p & 3
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
         const uint8_t *cb = cbuf[tb & 1];
         const int off0 = threadIdx.x * W;
         // xs[d] byte k = (code at byte 4d + k) << PSH: the entry offset of position q is one v_bfe_u32 (and one more
-        // for 64-byte entries)
+        // for 80-byte entries; 32-byte entries used to pay a shift per position too: byte = code * 16, -1.7 of 13 VALU per window)
         uint32_t xs[NWD];
 #pragma unroll
         for (int d = 0; d < NWD; ++d) xs[d] = (*reinterpret_cast<const uint32_t *>(cb + off0 + 4 * d) & 0x07070707u) << PSH;   // inside the halo
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
             case 2: asm("v_bfe_u32 %0, %1, 16, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
             default: asm("v_bfe_u32 %0, %1, 24, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
             }
-            if constexpr (ESTR == 32) off <<= 1;       // byte = code * 16
             if constexpr (ESTR == 80) off += off << 2;  // code * 16 * 5: one v_lshl_add_u32
             // position q feeds the windows u = q - 2k in [0, W], i.e. the row pairs k in [(q - W + 1) / 2, q / 2]: at most
             // W / 2 + 1 of the NJ dwords of its entry -- only the 16-byte groups that hold one of them are read
