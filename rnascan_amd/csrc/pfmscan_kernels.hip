@@ -1387,7 +1387,7 @@ static hipError_t launch_profile_t(const ScanArgs &a, const Tuning &t, hipStream
 {
     if (t.dma) {
         hipError_t e = hipSuccess;
-        if (t.v == 5 && launch_profile_fixed(a, stream, &e)) return e;        // all scores at a width with an unrolled instantiation
+        if (t.v == 5 && launch_profile_fixed(a, stream, &e)) return e;        // a width with an unrolled instantiation (all scores and the fused hits pass)
         if (t.v == 7) return launch_profile_v<7, HAS_SEQ, PROF_T, 2>(a, stream);
         return launch_profile_v<5, HAS_SEQ, PROF_T, 2>(a, stream);
     }

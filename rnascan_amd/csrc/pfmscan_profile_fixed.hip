@@ -1,4 +1,4 @@
-// pfmscan_profile_fixed.hip -- k_profile (codes + averaged-structure profile, all scores) with the
+// pfmscan_profile_fixed.hip -- k_profile (codes + averaged-structure profile: all scores and the fused hits pass) with the
 // PFM width as a COMPILE-TIME constant.  Same tile, same stager, same operation order and therefore the same bits as the
 // width-generic kernel in pfmscan_kernels.hip (rnascan.py:302-307 for the structure rows, _pwm.c:34-68 for the letters);
 // what the constant buys is VALU issue slots, the unit the headline kernel is shortest of once its bytes are moving:
@@ -6,7 +6,8 @@
 //     pointer (27 VALU instructions per wave and tile), every LDS offset an immediate of its ds_read;
 //   * the slide-in after the LAST row -- a row no window of the thread uses -- is not loaded or converted (7 + 4);
 //   * the piece counts of the stager and the layout of the output staging are constants.
-// Widths without an instantiation, hits mode and register staging run the generic kernel (launch_profile_fixed says no).
+// Widths without an instantiation (below 9 rows by measurement, above 18) and register staging run the generic kernel
+// (launch_profile_fixed says no).
 #include <cstdlib>
 #include "pfmscan_profile.hpp"
 
