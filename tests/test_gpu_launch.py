@@ -54,3 +54,22 @@ def test_rnascan_gpus_2_equals_one_rank(tmp_path):
     assert two.returncode == 0, two.stderr[-3000:]
     assert one.stdout.count("\n") > 50
     assert two.stdout == one.stdout
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("placement", ["tuned", "plain", "torch"])
+def test_bench_placements_give_the_same_line_but_for_the_time(placement):
+    """bench.py --placement tuned | plain | torch: the resident arrays come from pfmscan_place_alloc (measured / driver order) or
+    from torch's allocator; the line says which, the parity sample is bit-exact either way and the value is that of its time"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--records", "20000", "--steps", "3", "--warmup", "1", "--settle", "2",
+                        "--no-secondary", "--no-ref-structured", "--cpu-seconds", "1", "--placement", placement],
+                       env=_clean_env(PFMSCAN_BENCH_NO_FLOOR="1"), capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    pl = res["config"]["placement"]
+    assert pl["mode"] == placement, pl
+    if placement != "torch":
+        assert ("NOT tuned" in pl["note"]) == (placement == "plain"), pl
+    assert res["parity_on_sample"]["seq_f32_bit_exact"] is True and res["parity_on_sample"]["struct_within_1e-6"] is True
+    assert res["roofline"]["kernel"] == "k_profile_fixed"
+    assert res["value"] == pytest.approx(20000 * (3000 - 12 + 1) * 3 / (res["ms_per_step"] * 3e-3), rel=1e-6)
