@@ -6,9 +6,11 @@ Every source is compiled to its own object (in parallel, only when it or a heade
 changed), then linked.
 """
 import os
+import re
 import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,7 +67,48 @@ def build_lib(force=False, verbose=False):
     link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + \
            [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     run(link)
+    bad = runtime_indexed_registers(LIB)
+    if bad:
+        os.remove(LIB)
+        raise RuntimeError("kernels index registers at run time (see runtime_indexed_registers): %r" % bad)
     return LIB
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+# instructions that index the register file at run time (VGPR index mode, relative moves)
+_RUNTIME_INDEXED = re.compile(r"\b(s_set_gpr_idx_on|s_set_gpr_idx_idx|v_movrel[sd]+_b32|s_movrel[sd]_b(?:32|64))\b")
+
+
+def runtime_indexed_registers(path=LIB):
+    """Kernels of the gfx950 code objects in `path` that index registers at RUN TIME -> {kernel symbol: count}.
+
+    None of this library's kernels means to: every register array is indexed by constant expressions.  When one is not
+    (a loop the unroller left rolled), hipcc promotes the array to a register tuple, if-converts a guarded update
+    `if (0 <= u && u <= W) pk[u] += x` into an unconditional `s_set_gpr_idx_on u, gpr_idx(DST)` / `v_mov_b32` write and
+    does not clamp u: out-of-range indices overwrite unrelated live registers.  That was the wrong result of
+    k_letters_cred8<16> in round 4 (profiles/r5/NOTES.md; tools/gpr_idx_oob.hip isolates it), so a library in which the
+    pattern appears is refused."""
+    tmp = tempfile.mkdtemp(prefix="pfmscan_isa_")
+    try:
+        copy = os.path.join(tmp, os.path.basename(path))
+        shutil.copy(path, copy)
+        subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", copy], cwd=tmp, stdout=subprocess.DEVNULL)
+        found = {}
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            asm = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", os.path.join(tmp, f)],
+                                 capture_output=True, text=True, check=True).stdout
+            sym = "?"
+            for line in asm.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                if m:
+                    sym = m.group(1)
+                elif _RUNTIME_INDEXED.search(line):
+                    found[sym] = found.get(sym, 0) + 1
+        return found
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def build_floor_tool(force=False):

@@ -3,6 +3,7 @@
 #pragma once
 #include <float.h>
 #include <math.h>
+#include <type_traits>
 #include "pfmscan_internal.hpp"
 
 namespace pfmscan {
@@ -17,6 +18,21 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // code registers would otherwise spill)
 __host__ __device__ constexpr int let_iters(int ndw) { return ndw > 9 ? 2 : 4; }   // 8 rounds measured slower (occupancy 5)
 __host__ __device__ constexpr int let_tile(int ndw) { return BLOCK * 4 * let_iters(ndw); }
+
+// f(integral_constant<int, I>) for I = FIRST .. LAST - 1, expanded by the template machinery: the index is a constant
+// expression BY CONSTRUCTION.  Loops whose counter indexes a register array (pk[q - 2k] of the credit prefilters) use this
+// instead of `#pragma unroll`: when the unroller gives up on such a loop (it did for k_letters_cred8<16>: "loop not
+// unrolled"), the array is promoted to a vector register tuple that is indexed at run time, the guarded update
+// `if (0 <= u && u <= W) pk[u] += x` is if-converted into an UNCONDITIONAL s_set_gpr_idx_on / v_mov_b32 write with the
+// index not clamped, and for u outside the array that write lands on whatever register lives at v[base + u]
+// (profiles/r5/NOTES.md, tools/gpr_idx_oob.hip; rnascan_amd/build.py refuses a library that indexes VGPRs at run time).
+template <int FIRST, int LAST, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (FIRST < LAST) {
+        f(std::integral_constant<int, FIRST>{});
+        static_for<FIRST + 1, LAST>(f);
+    }
+}
 
 // numpy.nan_to_num defaults (rnascan.py:306): NaN -> 0, +-inf -> +-DBL_MAX.
 __device__ __forceinline__ double nan_to_num(double d)

@@ -600,8 +600,9 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
         uint32_t pk[W + 2];
 #pragma unroll
         for (int i = 0; i < W + 2; ++i) pk[i] = 0u;
-#pragma unroll
-        for (int q = 0; q < NPOS; ++q) {
+        // q and j are constant expressions (static_for, pfmscan_device.hpp): every pk[] / dj[] index is a register name
+        static_for<0, NPOS>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
             const uint32_t off = (q & 3) == 3 ? __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(xm[(q >> 2) + 1], xm[q >> 2], 3u), WT, 0u, false)
                                               : __builtin_amdgcn_udot4(xm[q >> 2], WT << (8 * (q & 3)), 0u, false);
             uint32_t dj[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -609,19 +610,20 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred(const ScanArgs a, const 
                 dj[0] = *reinterpret_cast<const entry_t *>(cbytes + off);
             } else if constexpr (NJ <= 4) {
                 const entry_t e = *reinterpret_cast<const entry_t *>(cbytes + off);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) dj[j] = e[j];
+                static_for<0, NJ>([&](auto jc) __attribute__((always_inline)) { dj[decltype(jc)::value] = e[decltype(jc)::value]; });
             } else {                                   // 5..8 row pairs: a 32-byte entry
                 const u32x4 e0 = *reinterpret_cast<const u32x4 *>(cbytes + off), e1 = *reinterpret_cast<const u32x4 *>(cbytes + off + 16);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) dj[j] = j < 4 ? e0[j] : e1[j - 4];
+                static_for<0, NJ>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    dj[j] = j < 4 ? e0[j & 3] : e1[j & 3];
+                });
             }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int wi = q - 2 - 4 * j;          // pack of the hi window w = q - 4j - 2
-                if (wi >= -2 && wi <= W - 1) pk[wi + 2] += dj[j];
-            }
-        }
+            static_for<0, NJ>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int wi = q - 2 - 4 * j;      // pack of the hi window w = q - 4j - 2
+                if constexpr (wi >= -2 && wi <= W - 1) pk[wi + 2] += dj[j];
+            });
+        });
         // The 16 sums two at a time: with A = P[w], B = P[w-2], C = P[w+2] one v_alignbit + one v_pk_add_u16 give
         // (sum(w) << 16 | sum(w+2)); bit 15 of a sum (they stay below 2^16) is its flag.  `surv` collects the flags of the
         // pair k = 0..7 -- windows 4 (k >> 1) + (k & 1) and that + 2 -- at bits 24 + k and 8 + k: two VALU instructions
@@ -830,8 +832,8 @@ __global__ __launch_bounds__(BLOCK) void k_letters_quad(const ScanArgs a)
         uint32_t pk[W + 4];
 #pragma unroll
         for (int i = 0; i < W + 4; ++i) pk[i] = 0u;
-#pragma unroll
-        for (int q = 0; q < NPOS; ++q) {
+        static_for<0, NPOS>([&](auto qc) __attribute__((always_inline)) {          // q, s2: constant expressions (see k_letters_cred)
+            constexpr int q = decltype(qc)::value;
             const uint32_t by = (q & 3) ? __builtin_amdgcn_alignbyte(xs[(q >> 2) + 1], xs[q >> 2], (uint32_t)(q & 3)) : xs[q >> 2];
             const uint32_t off = __builtin_amdgcn_udot4(by, 0x40100401u, 0u, false);      // 4-mer index x entry size
             uint32_t dw[4] = {0u, 0u, 0u, 0u};
@@ -839,15 +841,14 @@ __global__ __launch_bounds__(BLOCK) void k_letters_quad(const ScanArgs a)
                 dw[0] = *reinterpret_cast<const entry_t *>(qbytes + off);
             } else {
                 const entry_t e = *reinterpret_cast<const entry_t *>(qbytes + off);
-#pragma unroll
-                for (int s2 = 0; s2 < ND; ++s2) dw[s2] = e[s2];
+                static_for<0, ND>([&](auto sc) __attribute__((always_inline)) { dw[decltype(sc)::value] = e[decltype(sc)::value]; });
             }
-#pragma unroll
-            for (int s2 = 0; s2 < ND; ++s2) {
-                const int wi = q - 8 * s2 - 4;         // rows 2 s2 (lo: window wi + 4) and 2 s2 + 1 (hi: window wi)
-                if (wi >= -4 && wi <= W - 1) pk[wi + 4] += dw[s2];
-            }
-        }
+            static_for<0, ND>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int s2 = decltype(sc)::value;
+                constexpr int wi = q - 8 * s2 - 4;     // rows 2 s2 (lo: window wi + 4) and 2 s2 + 1 (hi: window wi)
+                if constexpr (wi >= -4 && wi <= W - 1) pk[wi + 4] += dw[s2];
+            });
+        });
         uint32_t sum[W];
         uint32_t any = 0;
 #pragma unroll

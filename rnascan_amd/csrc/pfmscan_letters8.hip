@@ -43,7 +43,7 @@ struct Cred8Table {
 constexpr int Q8_CAP = 128;                            // hits a wave can park (12 bytes each)
 
 template <int NJ>
-__global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
+__global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a)
 {
     constexpr int W = 16;                              // windows per lane = one round per tile
     constexpr int LET_TILE = BLOCK * W;
@@ -173,49 +173,51 @@ __global__ __launch_bounds__(BLOCK, 4) void k_letters_cred8(const ScanArgs a)
         uint32_t pk[W + 1];
 #pragma unroll
         for (int i = 0; i < W + 1; ++i) pk[i] = 0u;
-#pragma unroll
-        for (int q = 0; q < NPOS; ++q) {
+        // q, g and k are constant expressions (static_for, not `#pragma unroll`): every pk[] / dj[] index is a register name
+        static_for<0, NPOS>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
             // ONE v_bfe_u32 per position, written out: hipcc knows that only bits 5-7 of a byte can be set, narrows the
             // mask to 0xE0 and then no longer recognises the bit-field extract -- it issued a shift AND a mask per position,
             // 2 of the body's 9 VALU instructions per window
             uint32_t off;
-            switch (q & 3) {                            // q is an unrolled loop index: the switch folds
-            case 0: asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
-            case 1: asm("v_bfe_u32 %0, %1, 8, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
-            case 2: asm("v_bfe_u32 %0, %1, 16, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
-            default: asm("v_bfe_u32 %0, %1, 24, 8" : "=v"(off) : "v"(xs[q >> 2])); break;
-            }
+            if constexpr ((q & 3) == 0) asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(off) : "v"(xs[q >> 2]));
+            else if constexpr ((q & 3) == 1) asm("v_bfe_u32 %0, %1, 8, 8" : "=v"(off) : "v"(xs[q >> 2]));
+            else if constexpr ((q & 3) == 2) asm("v_bfe_u32 %0, %1, 16, 8" : "=v"(off) : "v"(xs[q >> 2]));
+            else asm("v_bfe_u32 %0, %1, 24, 8" : "=v"(off) : "v"(xs[q >> 2]));
             if constexpr (ESTR == 80) off += off << 2;  // code * 16 * 5: one v_lshl_add_u32
             // position q feeds the windows u = q - 2k in [0, W], i.e. the row pairs k in [(q - W + 1) / 2, q / 2]: at most
             // W / 2 + 1 of the NJ dwords of its entry -- only the 16-byte groups that hold one of them are read
             constexpr int KMAX = NJ - 1;
-            const int klo = q > W ? (q - W + 1) / 2 : 0, khi = q / 2 < KMAX ? q / 2 : KMAX;
+            constexpr int klo = q > W ? (q - W + 1) / 2 : 0, khi = q / 2 < KMAX ? q / 2 : KMAX;
             uint32_t dj[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             if constexpr (NJ <= 2) {
                 const u32x2 e = *reinterpret_cast<const u32x2 *>(cbytes + off);
                 dj[0] = e[0];
                 dj[1] = e[1];
             } else {
-#pragma unroll
-                for (int g = 0; g < (NJ + 3) / 4; ++g) {
-                    if (4 * g > khi || 4 * g + 3 < klo) continue;      // compile-time after unrolling
-                    if (NJ - 4 * g >= 3) {
-                        const u32x4 e = *reinterpret_cast<const u32x4 *>(cbytes + off + 16 * g);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) dj[4 * g + j] = e[j];
-                    } else {                           // a last group of two row pairs (NJ = 6)
-                        const u32x2 e = *reinterpret_cast<const u32x2 *>(cbytes + off + 16 * g);
-                        dj[4 * g] = e[0];
-                        dj[4 * g + 1] = e[1];
+                static_for<0, (NJ + 3) / 4>([&](auto gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (!(4 * g > khi || 4 * g + 3 < klo)) {
+                        if constexpr (NJ - 4 * g >= 3) {
+                            const u32x4 e = *reinterpret_cast<const u32x4 *>(cbytes + off + 16 * g);
+                            dj[4 * g] = e[0];
+                            dj[4 * g + 1] = e[1];
+                            dj[4 * g + 2] = e[2];
+                            dj[4 * g + 3] = e[3];
+                        } else {                       // a last group of two row pairs (NJ = 6)
+                            const u32x2 e = *reinterpret_cast<const u32x2 *>(cbytes + off + 16 * g);
+                            dj[4 * g] = e[0];
+                            dj[4 * g + 1] = e[1];
+                        }
                     }
-                }
+                });
             }
-#pragma unroll
-            for (int k = 0; k < NJ; ++k) {
-                const int u = q - 2 * k;               // rows 2k (lo: window u) and 2k + 1 (hi: window u - 1)
-                if (u >= 0 && u <= W) pk[u] += dj[k];
-            }
-        }
+            static_for<0, NJ>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int u = q - 2 * k;           // rows 2k (lo: window u) and 2k + 1 (hi: window u - 1)
+                if constexpr (u >= 0 && u <= W) pk[u] += dj[k];
+            });
+        });
         // The 16 sums two at a time: with A = P[w+1] one v_alignbit (lo(P[w]) << 16 | hi(P[w+2])) + one v_pk_add_u16 give
         // (sum(w) << 16 | sum(w+1)); bit 15 of a sum (they stay below 2^16) is its flag.  `surv` collects the flags of the
         // pair k = 0..7 (windows 2k and 2k + 1) at bits 24 + k and 8 + k: two VALU instructions per window, hits or not.

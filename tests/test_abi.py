@@ -66,3 +66,15 @@ def test_header_is_plain_c():
     import subprocess
     src = os.path.join(REPO, "tests", "c", "abi_smoke.c")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(REPO, "include"), src])
+
+
+def test_no_kernel_indexes_registers_at_run_time():
+    """The wrong result of k_letters_cred8<16> in round 4 (profiles/r5/NOTES.md): a register array indexed at run time gets
+    unclamped s_set_gpr_idx_on writes that land on other live registers.  The build refuses such a library; this keeps the
+    check itself honest (the shipped library is clean, the disassembler is found, the pattern is recognised)."""
+    from rnascan_amd import build
+    lib = build.build_lib()
+    assert build.runtime_indexed_registers(lib) == {}
+    assert build._RUNTIME_INDEXED.search("\ts_set_gpr_idx_on s12, gpr_idx(DST)")
+    assert build._RUNTIME_INDEXED.search("\tv_movreld_b32 v2, v75")
+    assert not build._RUNTIME_INDEXED.search("\tv_mov_b32_e32 v66, v2")

@@ -69,8 +69,9 @@ def test_hits_letters_f64_every_width(ctx, oracle, m):
 @pytest.mark.parametrize("nj", [4, 8, 10, 12, 16])
 def test_hits_letters_f64_every_bucket_of_the_prefilter(ctx, oracle, nj, monkeypatch):
     """every instantiation of k_letters_cred8 on PFMs narrower than it is sized for (rows beyond the width carry no
-    credit).  The widest one once came out of the compiler wrong when it was free to use more than 128 VGPRs; it is built
-    with a register cap since (profiles/r4/NOTES.md) and this is the test that showed it."""
+    credit).  The widest one once came out of the compiler wrong: its position loop was left rolled, pk[] became a register
+    tuple indexed at run time, and the if-converted guarded update wrote outside it (profiles/r5/NOTES.md).  The loops are
+    template-expanded since (static_for), the kernel is built WITHOUT a register cap again, and this is the test that showed it."""
     monkeypatch.setenv("PFMSCAN_CRED8_NJ", str(nj))
     for m in (3, 2 * nj - 1, 2 * nj):
         rng = np.random.default_rng(1000 + 10 * nj + m)
