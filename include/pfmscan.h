@@ -143,6 +143,10 @@ int pfmscan_scan_letters_f64_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
  * has both parts, the inner join of combine() (rnascan.py:422-423):
  *   hit  <=>  (no letter table  or seq(p)    > thr_seq)
  *         and (no struct pssm   or struct(p) > thr_struct)
+ * The structure compare is taken on the value the reference's arithmetic gives (rnascan.py:306: every product and
+ * every addition rounded, k ascending): a window whose fast score lies within 24 m 2^-53 1024 sum|pssm| of thr_struct
+ * is scored again in that order before the compare, and that score is reported (this holds for profile entries up to
+ * 1024 in magnitude; they are probabilities).  The same in every hits entry point of this header.
  * Hits are appended in no particular order:
  *   d_hit_pos int64 [capacity], d_hit_seq float [capacity] (or NULL),
  *   d_hit_struct double [capacity] (or NULL), d_hit_count: one uint64 the

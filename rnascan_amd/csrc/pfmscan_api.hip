@@ -224,6 +224,7 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
         mo->struct_finite = 1;
         for (int i = 0; i < m * 7; ++i)
             if (!std::isfinite(struct_pssm[i])) mo->struct_finite = 0;
+        mo->struct_band = struct_band(struct_pssm, m);
         e = hipMalloc((void **)&mo->d_struct, sizeof(double) * m * 7);
         if (e == hipSuccess) e = hipMemcpy(mo->d_struct, struct_pssm, sizeof(double) * m * 7, hipMemcpyHostToDevice);
     }
@@ -285,6 +286,7 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;
+    a.struct_band = mo->struct_band;
     a.ablate = ctx->tune.ablate;
     a.prio = ctx->tune.prio;
     a.dma_whole = ctx->tune.dma_whole;

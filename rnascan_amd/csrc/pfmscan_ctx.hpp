@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "pfmscan_internal.hpp"
+#include "pfmscan_exact.hpp"
 
 struct pfmscan_motif {
     pfmscan_ctx *ctx = nullptr;
@@ -23,6 +24,7 @@ struct pfmscan_motif {
     double *d_struct = nullptr;    // [m][7]
     int m = 0;
     int struct_finite = 0;
+    double struct_band = 0.0;      // pfmscan_exact.hpp: half-width of the re-score band of thresholded structure compares
 };
 
 namespace pfmscan {

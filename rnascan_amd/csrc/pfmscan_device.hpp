@@ -5,6 +5,7 @@
 #include <math.h>
 #include <type_traits>
 #include "pfmscan_internal.hpp"
+#include "pfmscan_exact.hpp"
 
 namespace pfmscan {
 

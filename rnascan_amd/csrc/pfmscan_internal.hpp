@@ -49,6 +49,8 @@ struct ScanArgs {
     const double *struct_pssm;   // [m][7] device or null
     int m;
     int struct_finite;           // every struct_pssm cell finite -> fast path legal
+    double struct_band;          // hits: |fast structure score - thr_struct| <= struct_band -> the window is scored again in the
+                                 // reference's rounded order before the compare (pfmscan_exact.hpp)
     // all-scores outputs (position aligned), any may be null
     float *out_seq;
     double *out_struct;
@@ -188,6 +190,7 @@ struct LibArgs {
     const double *pssm;                   // [m * 4][nmp][2] fp64: row j, column pair c/2, motif, c&1 (column 7 = 0); null = no structure side
     const double *thr_seq, *thr_struct;   // [nmp]
     int struct_finite;                    // every cell of every structure PSSM of the library is finite: phase B chains the row FMAs
+    double struct_band;                   // re-score band of the thresholded structure compare (max over the library's motifs, pfmscan_exact.hpp)
     int m, npair, nmp, ng, motif_base;
     int sort_batches;                     // A/B: phase B sorts each 64-item batch by motif group (PFMSCAN_LIB_SORT=1)
     int ng_real;                          // motif groups of the pass that hold motifs (<= ng, the layout of its tables): the rest is skipped
@@ -221,6 +224,7 @@ struct ProfLibArgs {
     int64_t n_pos;
     const double *pssm;                   // [n_motifs][m][7] fp64, row-major as handed to pfmscan_library_create
     const double *thr;                    // [n_motifs] structure thresholds (hit <=> score > thr, rnascan.py:310)
+    double struct_band;                   // re-score band of that compare (max over the library's motifs, pfmscan_exact.hpp)
     const int32_t *finite;                // [n_motifs] 1 = every cell of the motif's PSSM is finite
     int n_motifs, m, motif_base;
     int64_t pos_offset;                   // added to every reported hit position (chunked host pipeline)

@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(BLOCK, (V <= 3 ? 5 : (V <= 5 ? 4 : 3))) void k_prof
         if (keep == 1.2345e300) a.out_struct[0] = keep;
         return;
     }
+    if (HITS) settle_near<V, PROF_T>(a, reinterpret_cast<const PROF_T *>(smem), la, acc_st);
     if (HITS || (a.ablate & 8))
         emit_tile<V, HAS_SEQ, HITS>(a, tile0, la, acc_st, acc_sq, smem);
     else
@@ -1169,6 +1170,10 @@ __global__ __launch_bounds__(BLOCK) void k_struct_at(const ScanArgs a, const int
             else if (sizeof(PROF_T) == 4 && m > 12 && m <= 16) score = struct_score_at_wide<PROF_T, 4>(a.profile, p, m, a.struct_pssm);
             else if (sizeof(PROF_T) == 4 && m > 4 && m <= 8) score = struct_score_at_wide<PROF_T, 2>(a.profile, p, m, a.struct_pssm);
             else score = struct_score_at<PROF_T>(a.profile, p, m, a.struct_pssm);
+            if (struct_near(score, a.thr_struct, a.struct_band)) {       // too close to call: the reference's rounded order decides
+                const double *pssm = a.struct_pssm;
+                score = struct_window_rounded(reinterpret_cast<const PROF_T *>(a.profile) + p * 7, m, [&](int j, int k) { return pssm[j * 7 + k]; });
+            }
             mask = score > a.thr_struct ? 1u : 0u;
         }
         emit_hits_block<1>(mask, [&](int) { return p; }, [&](int) { return sq; }, [&](int) { return score; }, a);
@@ -1437,6 +1442,10 @@ __global__ __launch_bounds__(BLOCK) void k_wide(const ScanArgs a)
     }
     if (a.hits) {
         bool pass = in;
+        if (in && has_st && struct_near(st, a.thr_struct, a.struct_band)) {      // (NaN is never near)
+            const double *pssm = a.struct_pssm;
+            st = struct_window_rounded(reinterpret_cast<const PROF_T *>(a.profile) + p * 7, m, [&](int j, int k) { return pssm[j * 7 + k]; });
+        }
         if (has_st) pass = pass && (st > a.thr_struct);
         if (has_seq) pass = pass && ((a.f64_hits ? sq : (double)(float)sq) > a.thr_seq);
         // a letters-only scan reports its fp64 score in hit_struct (k_letters does), a scan with a structure part the structure score

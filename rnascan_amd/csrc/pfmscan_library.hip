@@ -36,6 +36,7 @@
 #include <math.h>
 
 #include "pfmscan_internal.hpp"
+#include "pfmscan_exact.hpp"
 
 namespace pfmscan {
 
@@ -513,6 +514,9 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
                         exact = !(fabs(st) <= DBL_MAX);                  // NaN / inf in the profile, or overflow: the per-row form decides
                     }
                     if (exact) st = lib_struct_score<PROF_T, NMP, false>(a.profile, ps, m, pssm, mo);
+                    if (struct_near(st, thr_t[mo], a.struct_band))       // too close to call: the reference's rounded order decides
+                        st = struct_window_rounded(reinterpret_cast<const PROF_T *>(a.profile) + ps * 7, m,
+                                                   [&](int j, int k) { return pssm[((size_t)(j * 4 + (k >> 1)) * NMP + mo) * 2 + (k & 1)]; });
                     ok = st > thr_t[mo];
                 }
             }

@@ -127,6 +127,7 @@ struct pfmscan_library {
     double *d_pssm_rows = nullptr;     // structure-only: [n][m][7] fp64 as handed in
     int32_t *d_finite = nullptr;       // structure-only: [n] 1 = every cell of the motif's PSSM is finite
     bool all_finite = false;           // seq + struct libraries: every cell of every structure PSSM is finite
+    double struct_band = 0.0;          // pfmscan_exact.hpp: re-score band of the thresholded structure compare, max over the motifs
     std::vector<double> pairsum;       // [n][npair][16] exact two-letter sums, index c0 | c1 << 2
     std::vector<LibPass> passes;
     uint16_t *d_pairs = nullptr;
@@ -160,6 +161,7 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
         lib->m = m;
         lib->has_struct = true;
         lib->has_letters = false;
+        for (int k = 0; k < n_motifs; ++k) lib->struct_band = std::max(lib->struct_band, struct_band(struct_pssms + (size_t)k * m * 7, m));
         std::vector<int32_t> fin((size_t)n_motifs, 1);
         for (int k = 0; k < n_motifs; ++k)
             for (int i = 0; i < m * 7; ++i)
@@ -192,6 +194,8 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
     lib->npair = (m + 1) / 2;
     lib->np_bucket = lib_np_bucket(m);
     lib->has_struct = struct_pssms != nullptr;
+    if (struct_pssms)
+        for (int k = 0; k < n_motifs; ++k) lib->struct_band = std::max(lib->struct_band, struct_band(struct_pssms + (size_t)k * m * 7, m));
     if (struct_pssms && !std::getenv("PFMSCAN_FORCE_GENERIC")) {
         lib->all_finite = true;
         for (size_t i = 0; i < (size_t)n_motifs * m * 7 && lib->all_finite; ++i) lib->all_finite = std::isfinite(struct_pssms[i]);
@@ -404,6 +408,7 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
         a.n_pos = n_pos;
         a.pssm = lib->d_pssm_rows;
         a.thr = lib->d_thr;
+        a.struct_band = lib->struct_band;
         a.finite = lib->d_finite;
         a.n_motifs = lib->n;
         a.m = lib->m;
@@ -481,6 +486,7 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
             a.thr_seq = lib->d_thr + ps.thr_off;
             a.thr_struct = lib->d_thr + ps.thr_off + ps.nmp;
             a.struct_finite = lib->all_finite ? 1 : 0;
+            a.struct_band = lib->struct_band;
             a.m = lib->m;
             a.npair = lib->npair;
             a.nmp = ps.nmp;

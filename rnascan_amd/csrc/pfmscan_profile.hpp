@@ -39,6 +39,24 @@ __device__ __forceinline__ double struct_window_slow(const PROF_T *prof_lds, int
     return score;
 }
 
+// Thresholded scans: the windows whose fast sum lies within a.struct_band of the threshold are scored again from the
+// staged tile in the reference's rounded order, so that `score > thr` is decided on the same value (pfmscan_exact.hpp)
+template <int V, typename PROF_T>
+__device__ __forceinline__ void settle_near(const ScanArgs &a, const PROF_T *prof_lds, int la, double (&acc_st)[V])
+{
+    const double thr = a.thr_struct, band = a.struct_band;
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < V; ++v) any = any || struct_near(acc_st[v], thr, band);
+    if (!any) return;
+    const double *pssm = a.struct_pssm;
+    static_for<0, V>([&](auto vc) __attribute__((always_inline)) {      // (a rolled loop would index acc_st[] at run time)
+        constexpr int v = decltype(vc)::value;
+        if (struct_near(acc_st[v], thr, band))
+            acc_st[v] = struct_window_rounded(prof_lds + (la + v) * 7, a.m, [&](int j, int k) { return pssm[j * 7 + k]; });
+    });
+}
+
 // LDS-DMA issued through inline asm.  hipcc cannot tell which LDS buffer a
 // `global_load_lds` writes, so with the builtin it drains vmcnt(0) before the
 // next ds_read and the prefetch never overlaps the scoring loop.  Inline asm is

@@ -133,8 +133,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_profile_fixed(const ScanArgs a)
     double acc_st[V], acc_sq[V];
     compute_tile_fixed<V, MW, HAS_SEQ, PROF_T, FINITE>(reinterpret_cast<const PROF_T *>(smem), smem + prof_bytes, tseq_lds, a.struct_pssm,
                                                        la, acc_st, acc_sq);
-    if (HITS)
+    if (HITS) {
+        settle_near<V, PROF_T>(a, reinterpret_cast<const PROF_T *>(smem), la, acc_st);
         emit_tile<V, HAS_SEQ, true>(a, tile0, la, acc_st, acc_sq, smem);      // the fused combined filter: seq > thr && struct > thr
+    }
     else
         emit_tile_wave<V, HAS_SEQ, PROF_T>(a, tile0, la, acc_st, acc_sq, smem, MW);
 }

@@ -32,6 +32,7 @@
 #include <math.h>
 
 #include "pfmscan_internal.hpp"
+#include "pfmscan_exact.hpp"
 
 namespace pfmscan {
 
@@ -309,18 +310,36 @@ __global__ __launch_bounds__(PL_BLOCK) void k_profile_lib(const ProfLibArgs a)
         else
             pl_score_motif<false>(tile, pssm, pssm_next, m, la, acc, P);
         fin = fin_next;
+        // The compare every window pays is against t - band: everything that may be a hit -- and ONE branch per motif on the
+        // OR over the thread's V windows (a branch per window cost the wave ~5 x 20 cycles per motif next to its 1700 of
+        // FMAs).  Behind it (rare) a window within the band of the threshold is scored again in the reference's rounded
+        // order, and that value decides and is reported (pfmscan_exact.hpp); the others pass on their fast score.
+        const double t_lo = t - a.struct_band, t_hi = t + a.struct_band;
+        bool maybe[V], any = false;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const bool pass = (la + v < live_n) && (acc[v] > t);
-            const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
-            if (mk) {                                  // wave-uniform
-                if (qn + 64 > PL_QCAP) flush();
-                if (pass) {
-                    const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                    q_sc[slot] = acc[v];
-                    q_wm[slot] = ((uint32_t)(la + v) << 16) | (uint32_t)k;
+            maybe[v] = (la + v < live_n) && (acc[v] > t_lo);
+            any = any || maybe[v];
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {          // wave-uniform
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                bool pass = maybe[v];
+                if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;                // wave-uniform
+                if (pass && acc[v] <= t_hi) {
+                    acc[v] = struct_window_rounded(tile + (la + v) * 7, m, [&](int j, int c) { return pssm[j * 7 + c]; });
+                    pass = acc[v] > t;
                 }
-                qn += __popcll(mk);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
+                if (mk) {                              // wave-uniform
+                    if (qn + 64 > PL_QCAP) flush();
+                    if (pass) {
+                        const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                        q_sc[slot] = acc[v];
+                        q_wm[slot] = ((uint32_t)(la + v) << 16) | (uint32_t)k;
+                    }
+                    qn += __popcll(mk);
+                }
             }
         }
         k = kn;
