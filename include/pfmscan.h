@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PFMSCAN_ABI_VERSION 7
+#define PFMSCAN_ABI_VERSION 8
 #define PFMSCAN_NCODE   8      /* columns of a letter table */
 #define PFMSCAN_SEP     7      /* separator / foreign-letter code */
 #define PFMSCAN_NSTRUCT 7      /* columns of a structure profile / structure PSSM */
@@ -337,6 +337,40 @@ int pfmscan_library_hits_pipeline_host(pfmscan_ctx *ctx, pfmscan_library *lib,
                                        int64_t n_pos, int64_t chunk_positions, const double *thr_seq,
                                        const double *thr_struct, int64_t capacity, int64_t *hit_pos,
                                        int32_t *hit_motif, float *hit_seq, double *hit_struct, int64_t *n_hits);
+
+/* ---- LETTER libraries: the structure side as letter strings (SURVEY 8f N1 x N4) -----------------------------------
+ * The reference scans structure FASTA files (`-q pfm structs.fa`, and `-p pfm -q pfm seqs.fa structs.fa`;
+ * rnascan.py:119-133) with _py_calculate (matrix.py:25-43: sequential sum of Python floats -- fp64, no float32 cast -- NaN
+ * on an unknown letter), one PFM per run (rnascan.py:262), though it ships a multi-PFM format (pfmutil.py:89-133).
+ *   struct_tables double [n][m][8]: letter tables of an alphabet of up to 7 letters (codes 0..6; column 7, the foreign
+ *   code / separator, must be NaN; unused columns NaN).
+ *   seq_tables == NULL: a STRUCTURE-LETTER library over ONE 8-code stream (`rnascan -q library structs.fa`), m <= 32.
+ *     Hit of motif k at window p <=> score_k(p) > thr_struct[k] (fp64 compare, strict: NaN and -inf never pass); the
+ *     score comes back in hit_struct, hit_seq is NaN / not written; thr_seq is ignored (may be NULL).  One pass per
+ *     128 motifs at w = 12: single-letter integer credits for eight motifs per 16-byte table entry (k_library8), exact
+ *     fp64 re-score of the survivors.
+ *   seq_tables double [n][m][8] (4-letter alphabet): a TWO-FASTA library over two code streams of the same layout (the
+ *     sequences and the structure strings of the same records), m <= 64.  Hit of pair k at window p <=>
+ *     (double)(float)seq_k(p) > thr_seq[k] on the first stream AND struct_k(p) > thr_struct[k] on the second -- the inner
+ *     join of combine() (rnascan.py:416-434).  k_library's prefilter on the sequence side; its survivors get the fp64
+ *     letter score of the second stream.
+ * Thresholds must be finite on the prefiltered side (thr_struct resp. thr_seq > -inf).  Scores are the numbers
+ * pfmscan_hits_letters_f64_* / pfmscan_hits_pair_* give for each motif (pair) alone.  Scanned through
+ * pfmscan_library_hits_staged (stage the stream with pfmscan_stage, the second one with pfmscan_stage_codes2) or the
+ * two entry points below; d_codes2 / codes2 are NULL for a structure-letter library. */
+int pfmscan_library_create_letters(pfmscan_ctx *ctx, const double *seq_tables,
+                                   const double *struct_tables, int n_motifs, int m,
+                                   pfmscan_library **out);
+int pfmscan_library_hits_letters_dev(pfmscan_ctx *ctx, pfmscan_library *lib,
+                                     const uint8_t *d_codes, const uint8_t *d_codes2, int64_t n_pos,
+                                     const double *thr_seq, const double *thr_struct, int64_t capacity,
+                                     int64_t *d_hit_pos, int32_t *d_hit_motif, float *d_hit_seq,
+                                     double *d_hit_struct, uint64_t *d_hit_count, void *stream);
+int pfmscan_library_hits_letters_host(pfmscan_ctx *ctx, pfmscan_library *lib,
+                                      const uint8_t *codes, const uint8_t *codes2, int64_t n_pos,
+                                      const double *thr_seq, const double *thr_struct, int64_t capacity,
+                                      int64_t *hit_pos, int32_t *hit_motif, float *hit_seq,
+                                      double *hit_struct, int64_t *n_hits);
 
 /* Diagnostics (host only, no device needed): the unsigned two-letter credit table the prefilters use for ONE motif
  * (letter_table double [m][8], 4-letter alphabet) at threshold thr_seq: credits uint16 [ceil(m/2)][16], entry index

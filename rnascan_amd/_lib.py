@@ -22,7 +22,7 @@ NCODE = 8
 NSTRUCT = 7
 MAX_M = 64            # widest PFM of the tuned kernels and of PFM libraries
 MAX_WIDTH = 4096      # widest PFM accepted (wider than MAX_M: the plain rolled-loop kernel)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/pfmscan.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -33,6 +33,7 @@ SYMBOLS = [
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
+    "pfmscan_library_create_letters", "pfmscan_library_hits_letters_dev", "pfmscan_library_hits_letters_host",
     "pfmscan_debug_quad_table", "pfmscan_debug_credit8_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
@@ -117,6 +118,9 @@ def load():
     L.pfmscan_hits_staged.argtypes = [vp, vp, dbl, dbl, i64, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_time_scan_dev.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, i32, i32, ctypes.POINTER(dbl)]
     L.pfmscan_library_create.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(vp)]
+    L.pfmscan_library_create_letters.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(vp)]
+    L.pfmscan_library_hits_letters_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.pfmscan_library_hits_letters_host.argtypes = [vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64)]
     L.pfmscan_library_destroy.argtypes = [vp]
     L.pfmscan_library_destroy.restype = None
     L.pfmscan_library_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32),
@@ -715,8 +719,18 @@ class Context(object):
                                                   _ptr(d_hit_struct), _ptr(d_hit_count), _ptr(stream)))
 
     # -- multi-PFM libraries (every motif in one pass) --------------------------------
-    def library(self, letter_tables, struct_pssms=None):
-        return Library(self, letter_tables, struct_pssms)
+    def library(self, letter_tables, struct_pssms=None, struct_letters=None):
+        return Library(self, letter_tables, struct_pssms, struct_letters)
+
+    def library_hits_letters_host(self, lib, codes, codes2=None, thr_seq=None, thr_struct=None, capacity=None):
+        """hits of a LETTER library (Library(struct_letters=...)): ``codes`` is the 8-code stream of a structure-letter library,
+        or the sequence codes of a two-FASTA library whose structure strings are ``codes2`` -> as library_hits_staged"""
+        if not lib.letter_kind:
+            raise ValueError("not a letter library")
+        self.stage(codes, None)
+        if lib.has_letters:
+            self.stage_codes2(codes2)
+        return self.library_hits_staged(lib, thr_seq, thr_struct, capacity)
 
     def library_hits_staged(self, lib, thr_seq, thr_struct=None, capacity=None):
         """hits of every motif of ``lib`` over the staged stream, sorted by (position, motif index)
@@ -867,16 +881,26 @@ class Motif(object):
 class Library(object):
     """n motifs of one width resident on the device for one-pass scans:
     letter_tables [n][m][8] (4-letter alphabet), struct_pssms [n][m][7] or None.
-    letter_tables None + struct_pssms: a STRUCTURE-ONLY library (k_profile_lib: every motif in one pass over the profile)."""
+    letter_tables None + struct_pssms: a STRUCTURE-ONLY library (k_profile_lib: every motif in one pass over the profile).
+    ``struct_letters`` [n][m][8] (up to 7 letters, fp64 scores) instead of struct_pssms: a LETTER library --
+    alone a structure-letter library over one 8-code stream (k_library8), with letter_tables a two-FASTA library over two
+    code streams (the structure letters of k_library's survivors)."""
 
-    def __init__(self, ctx, letter_tables, struct_pssms=None):
+    def __init__(self, ctx, letter_tables, struct_pssms=None, struct_letters=None):
         self._ctx = ctx
         self._L = ctx._L
         lt = None if letter_tables is None else np.ascontiguousarray(letter_tables, dtype=np.float64)
         if lt is not None and (lt.ndim != 3 or lt.shape[2] != NCODE):
             raise ValueError("letter_tables must be [n][m][8]")
         sp = None
-        if struct_pssms is not None:
+        self.letter_kind = struct_letters is not None
+        if self.letter_kind:
+            if struct_pssms is not None:
+                raise ValueError("struct_pssms and struct_letters exclude each other")
+            sp = np.ascontiguousarray(struct_letters, dtype=np.float64)
+            if sp.ndim != 3 or sp.shape[2] != NCODE or (lt is not None and sp.shape[:2] != lt.shape[:2]):
+                raise ValueError("struct_letters must be [n][m][8] with the letter tables' n and m")
+        elif struct_pssms is not None:
             sp = np.ascontiguousarray(struct_pssms, dtype=np.float64)
             if sp.ndim != 3 or sp.shape[2] != NSTRUCT or (lt is not None and sp.shape[:2] != lt.shape[:2]):
                 raise ValueError("struct_pssms must be [n][m][7] with the letter tables' n and m")
@@ -887,7 +911,10 @@ class Library(object):
         self.has_letters = lt is not None
         self.has_struct = sp is not None
         h = ctypes.c_void_p()
-        ctx._check(self._L.pfmscan_library_create(ctx._h, _ptr(lt), _ptr(sp), self.n, self.m, ctypes.byref(h)))
+        if self.letter_kind:
+            ctx._check(self._L.pfmscan_library_create_letters(ctx._h, _ptr(lt), _ptr(sp), self.n, self.m, ctypes.byref(h)))
+        else:
+            ctx._check(self._L.pfmscan_library_create(ctx._h, _ptr(lt), _ptr(sp), self.n, self.m, ctypes.byref(h)))
         self._h = h
 
     def thresholds(self, thr_seq, thr_struct=None):

@@ -216,6 +216,15 @@ size_t lib_lds_bytes(int m, int npair, int ng, bool has_struct, int np_bucket);
 int lib_np_bucket(int m);
 int lib_pick_ng(int np_bucket, int want_groups, int max_groups);   // supported group count of a pass (0: none fits)
 hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream);
+// LibArgs::profile_dtype of a two-FASTA library: `profile` is the SECOND code stream and `pssm` holds [m][8] letter tables
+constexpr int PROFILE_LETTERS2 = 100;
+// generic-alphabet letter libraries (k_library8): `pairs` = single-letter credits [rows][ng][8 codes][8 motifs] u16, `npair` =
+// lib8_rows(m) (the width rounded up to a multiple of 4), `pssm` = the exact tables [m * 4][nmp][2], thr_struct [nmp]; m <= 32
+__host__ __device__ constexpr int lib8_rows(int m) { return (m + 3) / 4 * 4; }
+size_t lib8_group_bytes(int m);
+size_t lib8_lds_bytes(int m, int ng);
+int lib8_pick_ng(int want_groups, int max_groups);
+hipError_t launch_library8(const LibArgs &a, int n_cu, hipStream_t stream);
 
 // ---- structure-only PFM library (pfmscan_proflib.hip): every motif in one pass over the profile ---------------------
 struct ProfLibArgs {

@@ -34,6 +34,7 @@
 // passes (256 pairs of width 12: passes of 96 / 96 / 64 motifs = 8 / 8 / 6 groups), each re-reading only the 1-byte codes.
 #include <float.h>
 #include <math.h>
+#include <type_traits>
 
 #include "pfmscan_internal.hpp"
 #include "pfmscan_exact.hpp"
@@ -146,6 +147,35 @@ __device__ __forceinline__ double lib_struct_score(const void *profile, int64_t 
     return score;
 }
 
+// Two-FASTA libraries (PROF_T = uint8_t: the "profile" is the SECOND code stream, the structure strings of the same records, and
+// the "PSSM" tables are [m][8] letter tables in the same LDS layout -- code c of row j at ((j * 4 + c / 2) * NMP + mo) * 2 + (c & 1),
+// column 7 = NaN): the fp64 letter score of matrix.py:25-43 at window p, a sequential sum with no float32 cast; a foreign
+// letter or separator makes it NaN, which never passes the strict `>` (rnascan.py:263).
+template <int NMP, int NP>
+__device__ __forceinline__ double lib_letters2_score(const uint8_t *__restrict__ codes2, int64_t p, int64_t n_pos, int m,
+                                                     const double *tab_lds, int mo)
+{
+    constexpr int NRAW = NP / 2 + 1;
+    const int64_t al = p & ~(int64_t)3;
+    uint32_t raw[NRAW];
+#pragma unroll
+    for (int k = 0; k < NRAW; ++k) raw[k] = (k < (m + 3) / 4 + 1) ? lib_codes4(codes2, al + 4 * k, n_pos) : 0u;
+    double st = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP / 2; ++k) {
+        const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = 4 * k + b;
+            if (j < m) {
+                const uint32_t c = (w >> (8 * b)) & 7u;
+                st += tab_lds[((size_t)(j * 4 + (int)(c >> 1)) * NMP + mo) * 2 + (c & 1u)];
+            }
+        }
+    }
+    return st;
+}
+
 // Credits of one motif group for the lane's window: K pair rows (compile-time), every look-up in flight before the
 // first add (8 rows at a time for wide PFMs), two rows per v_add3_u32.  rowp[t] points at the lane's entry of pair
 // row t in group 0; `off` (bytes, = group * 256) is an immediate when it is a constant.
@@ -215,7 +245,7 @@ __device__ __forceinline__ void lib_push(const u32x4 acc, const bool flag, const
 // Phase A, fast path: all NG groups of the lane's window, fully unrolled (immediate table offsets).  Pushes while
 // the queue has room; returns the first group that did NOT fit (NG when all did) -- from there the slow path takes
 // over after a drain.  A chunk brings one or two items per group at realistic thresholds, the queue takes >= 65.
-template <int K, int NG, int NP>
+template <int K, int NG, int NP, int GS = 256>      // GS: bytes of one motif group inside a table row (entries x 16)
 __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos, const uint32_t cw,
                                                uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1, const int ng_real)
 {
@@ -224,7 +254,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g >= ng_real) break;                      // wave-uniform: the groups from here on hold no motif
-        const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
+        const u32x4 acc = lib_credits<K, NP>(rowp, g * GS);
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
         if (mk && g_next == NG) {                     // wave-uniform
@@ -245,14 +275,14 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 
 // Phase A, slow path: groups g .. NG-1 one by one (runtime table offset), stopping as soon as 64 items wait.
 // Needs qn < 64 on entry (a group brings at most 64 items, the queue holds LIB_QCAP >= 127).
-template <int K, int NG, int NP>
+template <int K, int NG, int NP, int GS = 256>
 __device__ __forceinline__ int lib_octets_slow(int g, const lds_cptr (&rowp)[NP], int &qn, const uint32_t relpos, const uint32_t cw,
                                                uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1, const int ng_real)
 {
     int qs = __builtin_amdgcn_readfirstlane(qn);
     g = __builtin_amdgcn_readfirstlane(g);
     while (g < ng_real && qs < 64) {
-        const u32x4 acc = lib_credits<K, NP>(rowp, g * 256);
+        const u32x4 acc = lib_credits<K, NP>(rowp, g * GS);
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
         if (mk) {
@@ -508,15 +538,20 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 #else
                     const int64_t ps = p;
 #endif
-                    bool exact = !a.struct_finite;                       // wave-uniform
-                    if (a.struct_finite) {
-                        st = lib_struct_score<PROF_T, NMP, true>(a.profile, ps, m, pssm, mo);
-                        exact = !(fabs(st) <= DBL_MAX);                  // NaN / inf in the profile, or overflow: the per-row form decides
+                    if constexpr (std::is_same<PROF_T, uint8_t>::value) {
+                        // two-FASTA library: the structure LETTERS of the same window (rnascan.py:416-434 joins the two tables)
+                        st = lib_letters2_score<NMP, NP>(reinterpret_cast<const uint8_t *>(a.profile), ps, n_pos, m, pssm, mo);
+                    } else {
+                        bool exact = !a.struct_finite;                       // wave-uniform
+                        if (a.struct_finite) {
+                            st = lib_struct_score<PROF_T, NMP, true>(a.profile, ps, m, pssm, mo);
+                            exact = !(fabs(st) <= DBL_MAX);                  // NaN / inf in the profile, or overflow: the per-row form decides
+                        }
+                        if (exact) st = lib_struct_score<PROF_T, NMP, false>(a.profile, ps, m, pssm, mo);
+                        if (struct_near(st, thr_t[mo], a.struct_band))       // too close to call: the reference's rounded order decides
+                            st = struct_window_rounded(reinterpret_cast<const PROF_T *>(a.profile) + ps * 7, m,
+                                                       [&](int j, int k) { return pssm[((size_t)(j * 4 + (k >> 1)) * NMP + mo) * 2 + (k & 1)]; });
                     }
-                    if (exact) st = lib_struct_score<PROF_T, NMP, false>(a.profile, ps, m, pssm, mo);
-                    if (struct_near(st, thr_t[mo], a.struct_band))       // too close to call: the reference's rounded order decides
-                        st = struct_window_rounded(reinterpret_cast<const PROF_T *>(a.profile) + ps * 7, m,
-                                                   [&](int j, int k) { return pssm[((size_t)(j * 4 + (k >> 1)) * NMP + mo) * 2 + (k & 1)]; });
                     ok = st > thr_t[mo];
                 }
             }
@@ -696,6 +731,7 @@ template <int NG, int NP>
 static hipError_t launch_library_ng(const LibArgs &a, unsigned grid, size_t lds, hipStream_t stream)
 {
     if (!a.pssm) return launch_library_inst<NG, NP, float, false>(a, grid, lds, stream);
+    if (a.profile_dtype == PROFILE_LETTERS2) return launch_library_inst<NG, NP, uint8_t, true>(a, grid, lds, stream);     // two-FASTA library
     if (a.profile_dtype == PFMSCAN_PROFILE_F64) return launch_library_inst<NG, NP, double, true>(a, grid, lds, stream);
     return launch_library_inst<NG, NP, float, true>(a, grid, lds, stream);
 }
@@ -723,6 +759,259 @@ hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream)
     LIB_CASE(4, 32);
     LIB_CASE(2, 32);
 #undef LIB_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// k_library8 -- libraries of GENERIC-alphabet letter tables (up to 7 letters + the foreign code; the structure strings of
+// `rnascan -q struct_library structs.fa`, SURVEY 8f N1 x N4) in one pass over an 8-code stream.
+//
+// Reference semantics: matrix.py:25-43 (_py_calculate: sequential sum of Python floats, fp64, NO float32 cast; an unknown
+// letter makes the window NaN), rnascan.py:263 (hit <=> score > threshold, strict), pfmutil.py:89-133 (the multi-PFM format).
+//
+// k_library's machinery with ONE-letter table rows: row j of a motif group holds, for each of the 8 codes, the 16-bit credits
+// of that letter at motif position j for the group's EIGHT motifs (16 bytes; 8 entries = 128 bytes = 32 banks once: lanes with
+// the same letter read the same address, lanes with different letters different banks).  Rows are padded to a multiple of 4
+// with rows of full credit (the host builds the credits for the padded count: pfmscan_library_api.hip), so the row count is
+// one of 4 / 8 / 12 / 16 (/ 20 .. 32 in the wide bucket) and a compile-time constant of the unrolled look-ups.  The foreign
+// code and separators (7), NaN and -inf cells carry NO credit: such a window cannot reach the flag bit.  Bits 3-7 of a code
+// byte (bit 3 = "written in lower case") are ignored.  Phase B, 64 items at a time: the window's letters again (L2), the exact
+// fp64 sum from an LDS copy of the tables (the layout of k_library's structure tables: [m * 4][NMP][2]), fp64 compare.
+// NR = rows the code is unrolled for: 16 (m <= 16, 1024 threads) or 32 (m <= 32, 512 threads).
+// ---------------------------------------------------------------------------
+template <bool FAST, int NG, int NR>
+__device__ __forceinline__ int lib8_dispatch(const int rows, const int g, const lds_cptr (&rowp)[NR], int &qn, const uint32_t relpos,
+                                             uint32_t *q_pos, uint32_t *q_p0, uint32_t *q_p1, const int ng_real)
+{
+#define LIB8_ROWS(K)                                                                                              \
+    if (rows == K) {                                                                                              \
+        if (FAST) return lib_octets_fast<K, NG, NR, 128>(rowp, qn, relpos, 0u, q_pos, q_p0, q_p1, ng_real);       \
+        return lib_octets_slow<K, NG, NR, 128>(g, rowp, qn, relpos, 0u, q_pos, q_p0, q_p1, ng_real);              \
+    }
+    if constexpr (NR == 16) {
+        LIB8_ROWS(4) LIB8_ROWS(8) LIB8_ROWS(12)
+        if (FAST) return lib_octets_fast<16, NG, NR, 128>(rowp, qn, relpos, 0u, q_pos, q_p0, q_p1, ng_real);
+        return lib_octets_slow<16, NG, NR, 128>(g, rowp, qn, relpos, 0u, q_pos, q_p0, q_p1, ng_real);
+    } else {
+        LIB8_ROWS(20) LIB8_ROWS(24) LIB8_ROWS(28)
+        if (FAST) return lib_octets_fast<32, NG, NR, 128>(rowp, qn, relpos, 0u, q_pos, q_p0, q_p1, ng_real);
+        return lib_octets_slow<32, NG, NR, 128>(g, rowp, qn, relpos, 0u, q_pos, q_p0, q_p1, ng_real);
+    }
+#undef LIB8_ROWS
+}
+
+template <int NG, int NR>
+__global__ __launch_bounds__(lib_block(NR)) void k_library8(const LibArgs a)
+{
+    constexpr int LIB_BLOCK = lib_block(NR);
+    constexpr int LIB_WAVES = LIB_BLOCK / 64;
+    constexpr int MPG = 8;
+    constexpr int NMP = NG * MPG;
+    constexpr int NRAW = NR / 4 + 1;                 // aligned code dwords a lane loads: NR letters at any lane & 3
+    static_assert(lib_mpg(NR) == 8, "the (window, group) item format of the 16-bit credits");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int m = a.m, rows = a.npair;               // rows: m rounded up to a multiple of 4 (the padding rows are full credit)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- LDS carve-up (lib8_lds_bytes) ----
+    const int cred_bytes = rows * NG * 128;          // + one all-zero row of NG * 128 bytes: row 0 of the windows that do not exist
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cred = reinterpret_cast<uint32_t *>(smem + 16);
+    double *tab = reinterpret_cast<double *>(smem + 16 + cred_bytes + NG * 128);          // [m * 4][NMP][2]
+    double *thr_t = tab + (size_t)m * 8 * NMP;
+    uint32_t *qbase = reinterpret_cast<uint32_t *>(thr_t + NMP);
+    uint32_t *q_pos = qbase + (size_t)wave * LIB_QCAP * 3;
+    uint32_t *q_p0 = q_pos + LIB_QCAP;
+    uint32_t *q_p1 = q_p0 + LIB_QCAP;
+
+    for (int i = threadIdx.x; i < cred_bytes / 16; i += LIB_BLOCK)
+        reinterpret_cast<u32x4 *>(cred)[i] = reinterpret_cast<const u32x4 *>(a.pairs)[i];
+    for (int i = threadIdx.x; i < NG * 8; i += LIB_BLOCK) reinterpret_cast<u32x4 *>(cred)[cred_bytes / 16 + i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < m * 8 * NMP; i += LIB_BLOCK) tab[i] = a.pssm[i];
+    for (int i = threadIdx.x; i < NMP; i += LIB_BLOCK) thr_t[i] = a.thr_struct[i];
+    if (threadIdx.x == 0) *ticket = LIB_WAVES;
+    __syncthreads();                                // the only workgroup barrier
+
+    const int64_t n_pos = a.n_pos;
+    const int ng_real = a.ng_real;
+    const int shard = blockIdx.x & (a.hit_shards - 1);
+    unsigned long long *counter = a.hit_count + (size_t)shard * HIT_COUNTER_STRIDE;
+    const unsigned long long shard_off = (unsigned long long)shard * (unsigned long long)a.shard_cap;
+    const lds_cptr cred_lds = lds_ptr_of(cred);
+
+    // ---- phase B: the top cnt (<= 64) items of this wave's queue, one per lane and ONE motif per lane; what is left of an
+    // item goes back to the queue (k_library's eight-per-entry form: p0 / p1 = the sign bytes of the accumulators) ----
+    int requeued = 0;
+    auto dense = [&](int first, int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool have = lane < cnt;
+        const int idx = first + (have ? lane : 0);
+        const uint32_t rel = q_pos[idx], p0 = q_p0[idx], p1 = q_p1[idx];
+        const uint32_t g = p1 & 0x3Fu;
+        uint32_t bits = !have ? 0u : (((p0 >> 7) & 0x01010101u) | ((p1 >> 6) & 0x02020202u));
+        const int64_t p = a.pos_base + (int64_t)rel;
+        const bool act = bits != 0;
+        const int q = act ? __builtin_ctz(bits) : 0;
+        bits &= bits - 1;
+        const bool again = bits != 0;
+        const unsigned long long more = __builtin_amdgcn_ballot_w64(again);
+        if (more) {
+            if (again) {
+                const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                q_pos[slot] = rel;                  // slots first .. first + popc - 1 are being freed by this batch (all read above)
+                q_p0[slot] = (bits & 0x01010101u) << 7;
+                q_p1[slot] = ((bits & 0x02020202u) << 6) | g;
+            }
+            requeued = __popcll(more);
+        } else {
+            requeued = 0;
+        }
+        const int mo = (int)g * MPG + (q >> 3) + 4 * (q & 1);           // pass-local motif
+        // the window's letters again (L2: the wave read them a few chunks ago), then matrix.py:25-43: sequential fp64 sum
+        const int64_t al = p & ~(int64_t)3;
+        uint32_t raw[NRAW];
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) raw[k] = (k < (m + 3) / 4 + 1) ? lib_codes4(a.codes, al + 4 * k, n_pos) : 0u;
+        double sc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NR / 4; ++k) {
+            const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(p & 3));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = 4 * k + b;
+                if (j < m) {
+                    const uint32_t c = (w >> (8 * b)) & 7u;
+                    sc += tab[((size_t)(j * 4 + (int)(c >> 1)) * NMP + mo) * 2 + (c & 1u)];
+                }
+            }
+        }
+        const bool ok = act && (sc > thr_t[mo]);                          // fp64 compare: no float32 cast on this path
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(ok);
+        if (hm) {
+            const int nh = __popcll(hm);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(counter, (unsigned long long)nh);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+            base = ((unsigned long long)hi << 32) | lo;
+            if (ok) {
+                const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                if ((int64_t)slot < a.shard_cap) {
+                    a.hit_pos[shard_off + slot] = p + a.pos_offset;
+                    a.hit_motif[shard_off + slot] = a.motif_base + mo;
+                    if (a.hit_seq) a.hit_seq[shard_off + slot] = (float)sc;
+                    a.hit_struct[shard_off + slot] = sc;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- phase A: this workgroup's segments, this wave's 64-window chunks (LDS ticket, as in k_library) ----
+    int qn = 0;
+    constexpr int seg_shift = LIB_SEG_SHIFT - 6;
+    const int bid = (int)blockIdx.x, grid = (int)gridDim.x;
+    const int64_t my_segs = bid < a.n_seg ? (a.n_seg - bid + grid - 1) / grid : 0;
+    const uint32_t n_units = (uint32_t)(my_segs << seg_shift);
+    uint32_t drawn = 0;
+    auto next_unit = [&]() -> uint32_t {
+        if (lane == 0) drawn = atomicAdd(ticket, 1u);
+        return __builtin_amdgcn_readfirstlane(drawn);
+    };
+    for (uint32_t u = (uint32_t)wave; u < n_units; u = next_unit()) {
+        const int64_t rel0 = ((int64_t)((uint32_t)bid + (u >> seg_shift) * (uint32_t)grid) << (seg_shift + 6)) +
+                             (int64_t)((u & ((1u << seg_shift) - 1u)) << 6);
+        if (rel0 >= a.span) continue;                    // wave-uniform
+        const int64_t p0 = a.pos_base + rel0;            // multiple of 64
+        const int64_t al = p0 + (lane & ~3);
+        uint32_t raw[NRAW];
+        if (p0 + 64 + 4 * NRAW <= n_pos) {
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) raw[k] = *reinterpret_cast<const uint32_t *>(a.codes + al + 4 * k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) raw[k] = lib_codes4(a.codes, al + 4 * k, n_pos);
+        }
+        lds_cptr rowp[NR];
+#pragma unroll
+        for (int k = 0; k < NR / 4; ++k) {
+            const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)(lane & 3)) & 0x07070707u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)                  // (rows beyond `rows` are never looked up)
+                rowp[4 * k + b] = cred_lds + (4 * k + b) * (NG * 128) + (((w >> (8 * b)) & 7u) << 4);
+        }
+        // windows starting past the span belong to the next launch / do not exist: their row 0 is the zero row, and without the
+        // folded threshold the flag bit of their sums stays clear.  (Windows that run over the end of the stream hold code 7.)
+        if (rel0 + lane >= a.span) rowp[0] = cred_lds + cred_bytes;
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {                  // finished addresses: the group offset is the ds_read's immediate
+            uint32_t x = (uint32_t)(uintptr_t)rowp[t];
+            asm volatile("" : "+v"(x));
+            rowp[t] = (lds_cptr)(uintptr_t)x;
+        }
+        const uint32_t relpos = (uint32_t)(rel0 + lane);
+        int g = lib8_dispatch<true, NG, NR>(rows, 0, rowp, qn, relpos, q_pos, q_p0, q_p1, ng_real);
+        for (;;) {
+            while (qn >= 64) {                           // the top 64 items; the rest stays (LIFO)
+                dense(qn - 64, 64);
+                qn += requeued - 64;
+            }
+            if (g >= ng_real) break;
+            g = lib8_dispatch<false, NG, NR>(rows, g, rowp, qn, relpos, q_pos, q_p0, q_p1, ng_real);
+        }
+    }
+    while (qn > 0) {                                    // the tail
+        dense(0, qn);
+        qn = requeued;
+    }
+}
+
+// LDS bytes of one motif group of a k_library8 pass: its slice of every (padded) credit row and of the zero row, the exact
+// tables and thresholds of its 8 motifs
+size_t lib8_group_bytes(int m) { return (size_t)(lib8_rows(m) + 1) * 128 + 8 * ((size_t)m * 64 + 8); }
+size_t lib8_lds_bytes(int m, int ng) { return lib8_group_bytes(m) * (size_t)ng + lib_queue_bytes(m <= 16 ? 16 : 32); }
+
+static const int LIB8_NG[] = {16, 8, 4, 2};
+int lib8_pick_ng(int want_groups, int max_groups)
+{
+    int best = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (LIB8_NG[i] > max_groups) continue;
+        if (best == 0 || LIB8_NG[i] >= want_groups) best = LIB8_NG[i];
+    }
+    return best;
+}
+
+template <int NG, int NR>
+static hipError_t launch_library8_inst(const LibArgs &a, unsigned grid, size_t lds, hipStream_t stream)
+{
+    auto kern = k_library8<NG, NR>;
+    static std::atomic<uint64_t> configured{0};
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), configured, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(lib_block(NR)), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_library8(const LibArgs &a, int n_cu, hipStream_t stream)
+{
+    if (a.span <= 0 || a.nmp <= 0) return hipSuccess;
+    const size_t lds = lib8_lds_bytes(a.m, a.ng);
+    if (a.m < 1 || a.m > 32 || a.npair != lib8_rows(a.m) || lds > 160 * 1024 || a.ng * 8 != a.nmp ||
+        a.seg_positions != ((int64_t)1 << LIB_SEG_SHIFT) || ((a.n_seg + n_cu - 1) / n_cu) * (a.seg_positions >> 6) > 0x7FFFFFFF)
+        return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)std::min<int64_t>(a.n_seg, n_cu);
+#define LIB8_CASE(NGV)                                                                       \
+    if (a.ng == NGV) return a.m <= 16 ? launch_library8_inst<NGV, 16>(a, grid, lds, stream) \
+                                      : launch_library8_inst<NGV, 32>(a, grid, lds, stream)
+    LIB8_CASE(16);
+    LIB8_CASE(8);
+    LIB8_CASE(4);
+    LIB8_CASE(2);
+#undef LIB8_CASE
     return hipErrorInvalidValue;
 }
 

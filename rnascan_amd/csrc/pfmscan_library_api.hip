@@ -124,6 +124,9 @@ struct pfmscan_library {
     int n = 0, m = 0, npair = 0, np_bucket = 8;
     bool has_struct = false;
     bool has_letters = true;           // false: structure-only library (k_profile_lib, pfmscan_proflib.hip): one pass, no letter tables
+    bool pair = false;                 // two-FASTA library: the structure side is [m][8] letter tables over a SECOND code stream (k_library<.., uint8_t>)
+    bool letters8 = false;             // generic-alphabet letter library (k_library8): no sequence side, fp64 scores over an 8-code stream
+    std::vector<double> rows8;         // letters8: [n][lib8_rows(m)][8] table rows as the credits see them (NaN -> -inf, padding rows 0)
     double *d_pssm_rows = nullptr;     // structure-only: [n][m][7] fp64 as handed in
     int32_t *d_finite = nullptr;       // structure-only: [n] 1 = every cell of the motif's PSSM is finite
     bool all_finite = false;           // seq + struct libraries: every cell of every structure PSSM is finite
@@ -142,6 +145,11 @@ struct pfmscan_library {
 static int lib_fail(pfmscan_ctx *ctx, int code, const std::string &msg) { return fail(ctx, code, msg); }
 
 extern "C" {
+
+// sequence (4-letter) libraries, alone or with a structure side: ncol = 7 -> averaged-structure PSSMs [n][m][7] (k_library over
+// the profile), ncol = 8 -> structure LETTER tables [n][m][8] over a second code stream (two-FASTA library)
+static int create_seq_library(pfmscan_ctx *ctx, const double *letter_tables, const double *struct_pssms, int ncol, int n_motifs, int m,
+                              pfmscan_library **out);
 
 int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const double *struct_pssms, int n_motifs, int m,
                            pfmscan_library **out)
@@ -181,6 +189,14 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
         *out = lib;
         return PFMSCAN_OK;
     }
+    return create_seq_library(ctx, letter_tables, struct_pssms, 7, n_motifs, m, out);
+}
+
+}  // extern "C"
+
+static int create_seq_library(pfmscan_ctx *ctx, const double *letter_tables, const double *struct_pssms, int ncol, int n_motifs, int m,
+                              pfmscan_library **out)
+{
     for (int64_t i = 0; i < (int64_t)n_motifs * m; ++i)
         for (int c = 4; c < 8; ++c)
             if (!std::isnan(letter_tables[i * 8 + c]))
@@ -194,9 +210,10 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
     lib->npair = (m + 1) / 2;
     lib->np_bucket = lib_np_bucket(m);
     lib->has_struct = struct_pssms != nullptr;
-    if (struct_pssms)
+    lib->pair = struct_pssms != nullptr && ncol == 8;
+    if (struct_pssms && ncol == 7)
         for (int k = 0; k < n_motifs; ++k) lib->struct_band = std::max(lib->struct_band, struct_band(struct_pssms + (size_t)k * m * 7, m));
-    if (struct_pssms && !std::getenv("PFMSCAN_FORCE_GENERIC")) {
+    if (struct_pssms && ncol == 7 && !std::getenv("PFMSCAN_FORCE_GENERIC")) {
         lib->all_finite = true;
         for (size_t i = 0; i < (size_t)n_motifs * m * 7 && lib->all_finite; ++i) lib->all_finite = std::isfinite(struct_pssms[i]);
     }
@@ -248,8 +265,8 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
                 for (int c = 0; c < 4; ++c)
                     hl[ps.letters_off + (size_t)(j * 4 + c) * ps.nmp + l] = letter_tables[((size_t)k * m + j) * 8 + c];
                 if (lib->has_struct)
-                    for (int c = 0; c < 7; ++c)
-                        hp[ps.pssm_off + (((size_t)(j * 4 + c / 2)) * ps.nmp + l) * 2 + (c & 1)] = struct_pssms[((size_t)k * m + j) * 7 + c];
+                    for (int c = 0; c < ncol; ++c)
+                        hp[ps.pssm_off + (((size_t)(j * 4 + c / 2)) * ps.nmp + l) * 2 + (c & 1)] = struct_pssms[((size_t)k * m + j) * ncol + c];
             }
         }
     hipError_t e = hipMalloc((void **)&lib->d_pairs, pairs_elems * 2);
@@ -266,6 +283,91 @@ int pfmscan_library_create(pfmscan_ctx *ctx, const double *letter_tables, const 
     }
     *out = lib;
     return PFMSCAN_OK;
+}
+
+// generic-alphabet letter library (k_library8): [n][m][8] tables of up to 7 letters, fp64 scores, m <= 32
+static int create_letters8_library(pfmscan_ctx *ctx, const double *tables, int n_motifs, int m, pfmscan_library **out)
+{
+    if (m > 32) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "generic-alphabet library scans take PFMs up to 32 wide (scan wider ones one by one)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pfmscan_library *lib = new (std::nothrow) pfmscan_library();
+    if (!lib) return lib_fail(ctx, PFMSCAN_E_OOM, "out of host memory");
+    lib->ctx = ctx;
+    lib->n = n_motifs;
+    lib->m = m;
+    lib->npair = lib8_rows(m);
+    lib->np_bucket = m <= 16 ? 16 : 32;
+    lib->has_struct = true;             // its scores are reported (and thresholded) on the structure side: fp64
+    lib->has_letters = false;
+    lib->letters8 = true;
+    const int rows = lib->npair;
+    lib->rows8.assign((size_t)n_motifs * rows * 8, 0.0);
+    for (int k = 0; k < n_motifs; ++k)
+        for (int j = 0; j < m; ++j)
+            for (int c = 0; c < 8; ++c) {
+                const double v = tables[((size_t)k * m + j) * 8 + c];
+                // a NaN cell makes the window NaN, which never passes the strict `>` (rnascan.py:263): no credit, like -inf
+                lib->rows8[((size_t)k * rows + j) * 8 + c] = std::isnan(v) ? -INFINITY : v;
+            }
+    const size_t per_group = lib8_group_bytes(m);
+    const int fit_groups = (int)((160 * 1024 - lib_queue_bytes(lib->np_bucket) - 64) / per_group);
+    const int ng_max = lib8_pick_ng(1 << 20, fit_groups);
+    if (ng_max < 1) {
+        delete lib;
+        return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "PFM too wide for the library kernel's LDS tables");
+    }
+    size_t pairs_elems = 0, pssm_elems = 0, thr_elems = 0;
+    for (int base = 0; base < n_motifs;) {
+        LibPass ps;
+        ps.motif_base = base;
+        ps.n_real = std::min(n_motifs - base, ng_max * 8);
+        ps.ng_real = (ps.n_real + 7) / 8;
+        ps.ng = lib8_pick_ng(ps.ng_real, ng_max);
+        ps.nmp = ps.ng * 8;
+        ps.pairs_off = pairs_elems;
+        ps.pssm_off = pssm_elems;
+        ps.thr_off = thr_elems;
+        pairs_elems += (size_t)ps.ng * rows * 8 * 8;          // [row][group][8 codes][8 motifs] u16
+        pssm_elems += (size_t)m * 8 * ps.nmp;
+        thr_elems += (size_t)2 * ps.nmp;
+        base += ps.n_real;
+        lib->passes.push_back(ps);
+    }
+    lib->pairs_elems = pairs_elems;
+    lib->thr_elems = thr_elems;
+    std::vector<double> hp(pssm_elems, 0.0);                  // [m * 4][nmp][2]: code c of row j at ((j * 4 + c / 2) * nmp + l) * 2 + (c & 1)
+    for (const LibPass &ps : lib->passes)
+        for (int l = 0; l < ps.n_real; ++l)
+            for (int j = 0; j < m; ++j)
+                for (int c = 0; c < 8; ++c)
+                    hp[ps.pssm_off + (((size_t)(j * 4 + c / 2)) * ps.nmp + l) * 2 + (c & 1)] = tables[((size_t)(ps.motif_base + l) * m + j) * 8 + c];
+    hipError_t e = hipMalloc((void **)&lib->d_pairs, pairs_elems * 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&lib->d_pssm, pssm_elems * 8);
+    if (e == hipSuccess) e = hipMemcpy(lib->d_pssm, hp.data(), pssm_elems * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&lib->d_thr, thr_elems * 8);
+    if (e != hipSuccess) {
+        pfmscan_library_destroy(lib);
+        return fail_hip(ctx, e, "uploading the library tables");
+    }
+    *out = lib;
+    return PFMSCAN_OK;
+}
+
+extern "C" {
+
+int pfmscan_library_create_letters(pfmscan_ctx *ctx, const double *seq_tables, const double *struct_tables, int n_motifs, int m,
+                                   pfmscan_library **out)
+{
+    if (!ctx || !out || !struct_tables) return lib_fail(ctx, PFMSCAN_E_BADARG, "pfmscan_library_create_letters: NULL argument");
+    *out = nullptr;
+    if (n_motifs < 1 || n_motifs > 65535) return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "library size outside 1..65535");
+    if (m < 1 || m > PFMSCAN_MAX_M)
+        return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "PFM width " + std::to_string(m) + " outside 1.." + std::to_string(PFMSCAN_MAX_M));
+    for (int64_t i = 0; i < (int64_t)n_motifs * m; ++i)
+        if (!std::isnan(struct_tables[i * 8 + 7]))
+            return lib_fail(ctx, PFMSCAN_E_BADSHAPE, "column 7 of every letter table must be NaN (the foreign code)");
+    if (seq_tables) return create_seq_library(ctx, seq_tables, struct_tables, 8, n_motifs, m, out);
+    return create_letters8_library(ctx, struct_tables, n_motifs, m, out);
 }
 
 void pfmscan_library_destroy(pfmscan_library *lib)
@@ -326,7 +428,7 @@ int pfmscan_library_info(const pfmscan_library *lib, int *n_motifs, int *m, int 
 static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const double *thr_seq, const double *thr_struct, hipStream_t st)
 {
     const int n = lib->n, npair = lib->npair;
-    if (!lib->has_letters) {                              // structure-only: the thresholds are the only per-call table
+    if (!lib->has_letters && !lib->letters8) {            // structure-only: the thresholds are the only per-call table
         for (int k = 0; k < n; ++k)
             if (std::isnan(thr_struct[k])) return lib_fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
         if (lib->thr_valid && std::equal(thr_struct, thr_struct + n, lib->cur_struct.begin())) return PFMSCAN_OK;
@@ -335,6 +437,47 @@ static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const doub
         HIP_TRY(ctx, hipMemcpyAsync(lib->d_thr, lib->h_thr.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
         lib->cur_struct.assign(thr_struct, thr_struct + n);
         lib->eps.assign((size_t)n, 0.0);
+        lib->thr_valid = true;
+        return PFMSCAN_OK;
+    }
+    if (lib->letters8) {
+        // single-letter credits of every motif at its threshold: rows8 [rows][8] -> 16-bit credits, kernel layout
+        // [row][group][8 codes][4 dwords] with motif 2 d + h of the group in half h of dword d
+        const int rows = lib->npair;
+        for (int k = 0; k < n; ++k) {
+            if (std::isnan(thr_struct[k])) return lib_fail(ctx, PFMSCAN_E_BADARG, "NaN threshold");
+            if (thr_struct[k] == -INFINITY)
+                return lib_fail(ctx, PFMSCAN_E_BADARG, "library hits need a finite threshold (every window would be a hit; use the all-scores entry points)");
+        }
+        if (lib->thr_valid && std::equal(thr_struct, thr_struct + n, lib->cur_struct.begin())) return PFMSCAN_OK;
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        lib->thr_valid = false;
+        lib->h_pairs.assign(lib->pairs_elems, (uint16_t)0);
+        lib->h_thr.assign(lib->thr_elems, 0.0);
+        lib->eps.assign((size_t)n, 0.0);
+        std::vector<uint16_t> cr((size_t)rows * 8);
+        uint32_t *words = reinterpret_cast<uint32_t *>(lib->h_pairs.data());
+        for (const LibPass &ps : lib->passes)
+            for (int l = 0; l < ps.nmp; ++l) {
+                const int g = l / 8, slot = l % 8;
+                if (l >= ps.n_real) {                     // padding motif: all credits 0, never flagged
+                    lib->h_thr[ps.thr_off + l] = INFINITY;
+                    lib->h_thr[ps.thr_off + ps.nmp + l] = INFINITY;
+                    continue;
+                }
+                const int k = ps.motif_base + l;
+                lib->h_thr[ps.thr_off + l] = thr_struct[k];
+                lib->h_thr[ps.thr_off + ps.nmp + l] = thr_struct[k];
+                lib->eps[k] = build_credits(lib->rows8.data() + (size_t)k * rows * 8, rows, thr_struct[k], cr.data(), 16, 8);
+                for (int t = 0; t < rows; ++t)
+                    for (int i = 0; i < 8; ++i) {
+                        uint32_t *entry = words + ps.pairs_off / 2 + (((size_t)t * ps.ng + g) * 8 + i) * 4;
+                        entry[slot / 2] |= (uint32_t)cr[t * 8 + i] << (16 * (slot % 2));
+                    }
+            }
+        HIP_TRY(ctx, hipMemcpyAsync(lib->d_pairs, lib->h_pairs.data(), lib->pairs_elems * 2, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(lib->d_thr, lib->h_thr.data(), lib->thr_elems * 8, hipMemcpyHostToDevice, st));
+        lib->cur_struct.assign(thr_struct, thr_struct + n);
         lib->thr_valid = true;
         return PFMSCAN_OK;
     }
@@ -386,6 +529,8 @@ static int lib_set_thresholds(pfmscan_ctx *ctx, pfmscan_library *lib, const doub
 
 constexpr int64_t LIB_SEG = (int64_t)1 << LIB_SEG_SHIFT;        // windows per work segment (segment s -> workgroup s mod grid, shard s mod 256)
 
+static int64_t lib_work_unit(const pfmscan_library *lib);
+
 struct LibSink {
     int64_t *pos;
     int32_t *motif;
@@ -400,6 +545,42 @@ struct LibSink {
 static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const void *d_profile, int profile_dtype,
                    int64_t n_pos, const LibSink &sink, hipStream_t st, int64_t pos_offset = 0)
 {
+    if (lib->letters8) {
+        // generic-alphabet letter library: its passes one after the other (each re-reads only the 1-byte codes)
+        const int64_t max_span = (int64_t)1 << 31;
+        for (int64_t base = 0; base < n_pos; base += max_span)
+            for (const LibPass &ps : lib->passes) {
+                LibArgs a;
+                std::memset(&a, 0, sizeof(a));
+                a.codes = d_codes;
+                a.n_pos = n_pos;
+                a.pos_base = base;
+                a.span = std::min<int64_t>(max_span, n_pos - base);
+                a.seg_positions = LIB_SEG;
+                a.n_seg = (a.span + a.seg_positions - 1) / a.seg_positions;
+                a.pairs = reinterpret_cast<const uint32_t *>(lib->d_pairs + ps.pairs_off);
+                a.pssm = lib->d_pssm + ps.pssm_off;
+                a.thr_seq = lib->d_thr + ps.thr_off;
+                a.thr_struct = lib->d_thr + ps.thr_off + ps.nmp;
+                a.m = lib->m;
+                a.npair = lib->npair;
+                a.nmp = ps.nmp;
+                a.ng = ps.ng;
+                a.ng_real = ps.ng_real;
+                a.motif_base = ps.motif_base;
+                a.pos_offset = pos_offset;
+                a.shard_cap = sink.shard_cap;
+                a.hit_shards = sink.shards;
+                a.hit_pos = sink.pos;
+                a.hit_motif = sink.motif;
+                a.hit_seq = nullptr;
+                a.hit_struct = sink.st;
+                a.hit_count = sink.count;
+                hipError_t e = launch_library8(a, ctx->n_cu, st);
+                if (e != hipSuccess) return fail_hip(ctx, e, "launch k_library8");
+            }
+        return PFMSCAN_OK;
+    }
     if (!lib->has_letters) {
         ProfLibArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -432,7 +613,7 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
     // hardware queue each and workgroup counts that are multiples of 8 per kernel (a grid is dealt round-robin to the 8
     // XCDs and one workgroup too many on an XCD waits for a whole persistent kernel) -- 29 ms instead of 10.
     const LibPass &first_pass = lib->passes[0];
-    bool teams = lib->has_struct && lib->passes.size() > 1 && n_pos >= (int64_t)8 * ctx->n_cu * LIB_SEG &&
+    bool teams = lib->has_struct && !lib->pair && lib->passes.size() > 1 && n_pos >= (int64_t)8 * ctx->n_cu * LIB_SEG &&
                  ctx->n_cu >= 16 && !std::getenv("PFMSCAN_LIB_SEQUENTIAL");
     for (const LibPass &ps : lib->passes) teams = teams && ps.ng == first_pass.ng;      // the common layout (pfmscan_library_create)
     const int64_t max_span = (int64_t)1 << 31;
@@ -473,8 +654,8 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
                 a.stride_thr = (int64_t)(lib->passes[p0 + 1].thr_off - ps.thr_off);
             }
             a.codes = d_codes;
-            a.profile = lib->has_struct ? d_profile : nullptr;
-            a.profile_dtype = profile_dtype;
+            a.profile = lib->has_struct ? d_profile : nullptr;       // (two-FASTA library: the second code stream)
+            a.profile_dtype = lib->pair ? PROFILE_LETTERS2 : profile_dtype;
             a.n_pos = n_pos;
             a.pos_base = base;
             a.span = std::min<int64_t>(max_span, n_pos - base);
@@ -507,6 +688,9 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
     return PFMSCAN_OK;
 }
 
+// positions one workgroup-visit covers: sizes the shards of the hit buffers
+static int64_t lib_work_unit(const pfmscan_library *lib) { return (lib->has_letters || lib->letters8) ? LIB_SEG : profile_library_tile(); }
+
 static int lib_check(pfmscan_ctx *ctx, const pfmscan_library *lib, const uint8_t *codes, const void *profile, int profile_dtype,
                      int64_t n_pos, const double *thr_seq, const double *thr_struct)
 {
@@ -515,6 +699,14 @@ static int lib_check(pfmscan_ctx *ctx, const pfmscan_library *lib, const uint8_t
     if (n_pos < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative n_pos");
     if ((lib->has_letters && !thr_seq) || (lib->has_struct && !thr_struct)) return lib_fail(ctx, PFMSCAN_E_BADARG, "threshold arrays are NULL");
     if (n_pos > 0 && lib->has_letters && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    if (lib->letters8) {
+        if (n_pos > 0 && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+        return PFMSCAN_OK;
+    }
+    if (lib->pair) {
+        if (n_pos > 0 && !profile) return lib_fail(ctx, PFMSCAN_E_BADARG, "two-FASTA library: the second code stream is NULL");
+        return PFMSCAN_OK;
+    }
     if (lib->has_struct) {
         if (profile_dtype != PFMSCAN_PROFILE_F32 && profile_dtype != PFMSCAN_PROFILE_F64)
             return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs: profile_dtype must be F32 or F64");
@@ -604,7 +796,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_lib_pack(const int64_t *__restri
     const int64_t src = (int64_t)lo * shard_cap + (i - start[lo]);
     pos[i] = s_pos[src];
     if (motif) motif[i] = s_motif[src];
-    if (seq) seq[i] = s_seq[src];
+    if (seq) seq[i] = s_seq ? s_seq[src] : __builtin_nanf("");      // a library without a sequence side reports NaN there
     if (st && s_st) st[i] = s_st[src];
 }
 
@@ -697,7 +889,7 @@ int pfmscan_library_hits_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
     LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib_work_unit(lib)))) return rc;
     const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
     HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
     if ((rc = lib_run(ctx, lib, d_codes, d_profile, profile_dtype, n_pos, sink, st))) return rc;
@@ -722,10 +914,14 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     if (!n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
     if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
     if (ctx->staged_n < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "no stream staged (call pfmscan_stage first)");
-    if (lib->has_letters && !ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
-    if (lib->has_struct && !ctx->staged_profile && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but no profile is staged");
+    if ((lib->has_letters || lib->letters8) && !ctx->staged_codes && ctx->staged_n > 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "library scans need staged codes");
+    if (lib->pair && !ctx->staged_codes2 && ctx->staged_n > 0)
+        return lib_fail(ctx, PFMSCAN_E_BADARG, "two-FASTA library: two code streams must be staged (pfmscan_stage + pfmscan_stage_codes2)");
+    if (lib->has_struct && !lib->pair && !lib->letters8 && !ctx->staged_profile && ctx->staged_n > 0)
+        return lib_fail(ctx, PFMSCAN_E_BADARG, "library has structure PSSMs but no profile is staged");
     const int64_t n_pos = ctx->staged_n;
-    int rc = lib_check(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, thr_seq, thr_struct);
+    const void *second = lib->pair ? ctx->codes2.p : ctx->profile.p;     // the structure side's stream: profile rows, or the second code stream
+    int rc = lib_check(ctx, lib, (const uint8_t *)ctx->codes.p, second, ctx->staged_dtype, n_pos, thr_seq, thr_struct);
     if (rc) return rc;
     if (capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
     *n_hits = 0;
@@ -735,11 +931,38 @@ int pfmscan_library_hits_staged(pfmscan_ctx *ctx, pfmscan_library *lib, const do
     hipStream_t st = ctx->stream;
     if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
     LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib_work_unit(lib)))) return rc;
     const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
     HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));
-    if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->codes.p, ctx->profile.p, ctx->staged_dtype, n_pos, sink, st))) return rc;
+    if ((rc = lib_run(ctx, lib, (const uint8_t *)ctx->codes.p, second, ctx->staged_dtype, n_pos, sink, st))) return rc;
     return lib_finish_sorted(ctx, lib, n_pos, capacity, sink, hit_pos, hit_motif, hit_seq, hit_struct, n_hits);
+}
+
+int pfmscan_library_hits_letters_dev(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_codes, const uint8_t *d_codes2,
+                                     int64_t n_pos, const double *thr_seq, const double *thr_struct, int64_t capacity,
+                                     int64_t *d_hit_pos, int32_t *d_hit_motif, float *d_hit_seq, double *d_hit_struct,
+                                     uint64_t *d_hit_count, void *stream)
+{
+    if (!ctx || !lib) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL ctx or library");
+    if (!lib->letters8 && !lib->pair) return lib_fail(ctx, PFMSCAN_E_BADARG, "not a letter library (pfmscan_library_create_letters)");
+    return pfmscan_library_hits_dev(ctx, lib, d_codes, lib->pair ? (const void *)d_codes2 : nullptr, PFMSCAN_PROFILE_NONE, n_pos, thr_seq,
+                                    thr_struct, capacity, d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct, d_hit_count, stream);
+}
+
+int pfmscan_library_hits_letters_host(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *codes, const uint8_t *codes2, int64_t n_pos,
+                                      const double *thr_seq, const double *thr_struct, int64_t capacity, int64_t *hit_pos,
+                                      int32_t *hit_motif, float *hit_seq, double *hit_struct, int64_t *n_hits)
+{
+    if (!ctx || !lib || !n_hits) return lib_fail(ctx, PFMSCAN_E_BADARG, "NULL argument");
+    if (!lib->letters8 && !lib->pair) return lib_fail(ctx, PFMSCAN_E_BADARG, "not a letter library (pfmscan_library_create_letters)");
+    if (n_pos < 0 || capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
+    *n_hits = 0;
+    if (n_pos == 0) return PFMSCAN_OK;
+    if (!codes || (lib->pair && !codes2)) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
+    int rc = pfmscan_stage(ctx, codes, nullptr, PFMSCAN_PROFILE_NONE, n_pos);
+    if (rc) return rc;
+    if (lib->pair && (rc = pfmscan_stage_codes2(ctx, codes2, n_pos))) return rc;
+    return pfmscan_library_hits_staged(ctx, lib, thr_seq, thr_struct, capacity, hit_pos, hit_motif, hit_seq, hit_struct, n_hits);
 }
 
 // The library twin of pfmscan_hits_pipeline_host (pfmscan_pipeline.hip): a HOST-resident stream of any length, chunk by
@@ -755,6 +978,8 @@ int pfmscan_library_hits_pipeline_host(pfmscan_ctx *ctx, pfmscan_library *lib, c
     if (n_pos < 0 || capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
     *n_hits = 0;
     if (n_pos == 0) return PFMSCAN_OK;
+    if (lib->letters8 || lib->pair)
+        return lib_fail(ctx, PFMSCAN_E_BADARG, "letter libraries scan staged code streams (1 byte per position): pfmscan_library_hits_letters_host");
     int rc = lib_check(ctx, lib, codes, profile, profile_dtype, n_pos, thr_seq, thr_struct);
     if (rc) return rc;
     if (capacity > 0 && (!hit_pos || !hit_motif)) return lib_fail(ctx, PFMSCAN_E_BADARG, "hit_pos / hit_motif is NULL");
@@ -775,7 +1000,7 @@ int pfmscan_library_hits_pipeline_host(pfmscan_ctx *ctx, pfmscan_library *lib, c
     hipStream_t st = ctx->stream;
     if ((rc = lib_set_thresholds(ctx, lib, thr_seq, thr_struct, st))) return rc;
     LibSink sink;
-    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib->has_letters ? LIB_SEG : profile_library_tile()))) return rc;
+    if ((rc = lib_scratch(ctx, capacity, n_pos, sink, lib_work_unit(lib)))) return rc;
     const size_t counter_bytes = (size_t)LIB_SHARDS * HIT_COUNTER_STRIDE * 8;
     HIP_TRY(ctx, hipMemsetAsync(sink.count, 0, counter_bytes, st));          // cleared once: the chunks' hits accumulate
 
@@ -816,6 +1041,7 @@ int pfmscan_library_hits_host(pfmscan_ctx *ctx, pfmscan_library *lib, const uint
     if (n_pos < 0 || capacity < 0) return lib_fail(ctx, PFMSCAN_E_BADARG, "negative size");
     *n_hits = 0;
     if (n_pos == 0) return PFMSCAN_OK;
+    if (lib->letters8 || lib->pair) return lib_fail(ctx, PFMSCAN_E_BADARG, "letter library: use pfmscan_library_hits_letters_host");
     if (lib->has_letters && !codes) return lib_fail(ctx, PFMSCAN_E_BADARG, "codes is NULL");
     if (lib->has_struct && !profile) return lib_fail(ctx, PFMSCAN_E_BADARG, "profile is NULL");
     int rc = pfmscan_stage(ctx, lib->has_letters ? codes : nullptr, lib->has_struct ? profile : nullptr, profile_dtype, n_pos);
