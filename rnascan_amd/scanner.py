@@ -21,6 +21,7 @@ from .pssm import PSSM
 SEQ_COLUMNS = ["Sequence_ID", "Description", "Motif_ID", "Start", "End", "Sequence", "LogOdds"]
 PIPELINE_CHUNK = int(os.environ.get("RNASCAN_PIPELINE_CHUNK", str(1 << 24)))     # positions per chunk of the host pipeline
 LIBRARY_MAX_M = 64                                                                # PFMSCAN_MAX_M: wider PFMs are scanned one by one (the plain kernel)
+LETTER_LIBRARY_MAX_M = 32                                                         # structure-letter libraries (k_library8): wider PFMs one by one
 PIPELINE_MIN = 2 * PIPELINE_CHUNK                                                 # shorter streams are staged whole
 
 
@@ -145,6 +146,29 @@ def _library_hits(self, stream, letter_tables, struct_pssms, thr_seq, thr_struct
 
 
 HipEngine.library_hits = _library_hits
+
+
+def _library_hits_letters(self, stream, seq_tables, struct_tables, thr_seq, thr_struct):
+    """hits of EVERY motif of a LETTER library in one pass (SURVEY 8f N1 x N4): struct_tables [n][m][8] (up to 7 letters,
+    fp64 scores) over ``stream.codes`` -- a structure-letter library, k_library8 -- or, with seq_tables [n][m][8]
+    (nucleotides), pair k = (sequence PFM k over ``stream.codes``, structure-letter PFM k over ``stream.codes2``): the
+    two-FASTA library.  -> (pos, motif index, seq float32 | None, struct float64) sorted by (pos, motif index)."""
+    T = None if seq_tables is None else np.ascontiguousarray(seq_tables, dtype=np.float64)
+    S = np.ascontiguousarray(struct_tables, dtype=np.float64)
+    key = ("letters", S.shape, None if T is None else T.tobytes(), S.tobytes())
+    if self._library is None or self._library[0] != key:
+        if self._library is not None:
+            self._library[1].close()
+            self._library = None
+        self._library = (key, self.ctx.library(T, struct_letters=S))
+    self._stage(stream)
+    if T is not None and self._staged2 is not stream:
+        self.ctx.stage_codes2(stream.codes2)
+        self._staged2 = stream
+    return self.ctx.library_hits_staged(self._library[1], thr_seq, thr_struct)
+
+
+HipEngine.library_hits_letters = _library_hits_letters
 
 
 def _first_motif(pssm):
@@ -310,6 +334,13 @@ def scan_records(engine, records, pssm, letters, minscore, columns=False):
             T = np.stack([pssm[i].letter_table(order) for i in mids])
             pos, mo, sq, _ = engine.library_hits(stream, T, None, float(minscore), one_shot=len(by_width) == 1)
             tables.append(rows(mids, m, pos, mo, np.round(sq, 3)))
+            continue
+        if not is_rna and len(mids) > 1 and np.isfinite(float(minscore)) and m <= LETTER_LIBRARY_MAX_M and \
+                hasattr(engine, "library_hits_letters"):
+            # a structure-letter library (`-q library structs.fa`): one pass per width too (k_library8), scores in fp64
+            T = np.stack([pssm[i].letter_table(order) for i in mids])
+            pos, mo, _, sc = engine.library_hits_letters(stream, None, T, None, float(minscore))
+            tables.append(rows(mids, m, pos, mo, _lib.round_decimals(sc, 3)))
             continue
         for motif_id in mids:
             tab = pssm[motif_id].letter_table(order)
@@ -576,25 +607,39 @@ def scan_pair(engine, seq_records, struct_records, seq_pssm, struct_pssm, minsco
     stream = pack.Stream(sb.codes, None, sb.offsets, sb.lengths, codes2=tb.codes)
     thr = float(minscore)
     tables = []
-    for a, b in pairs_m:
-        m = seq_pssm[a].length
-        tab_seq = seq_pssm[a].letter_table(pack.RNA_LETTERS)
-        tab_st = struct_pssm[b].letter_table(fasta.STRUCT)
-        if np.isneginf(thr) or not hasattr(engine, "hits_pair"):
-            # every window with two finite scores is a row: all scores of both sides, the same strict `>` on the host
-            sq, _ = engine.scan(stream, tab_seq, None)
-            st = engine.scan_letters_f64(pack.Stream(tb.codes, None, tb.offsets, tb.lengths), tab_st)
-            pos = np.flatnonzero(stream.window_mask(m) & (sq.astype(np.float64) > thr) & (st > thr))
-            sq, st = sq[pos], st[pos]
-        else:
-            pos, sq, st = engine.hits_pair(stream, tab_seq, tab_st, thr, thr)
+
+    def rows(pos, sq, st, m, seq_ids, struct_ids):
         rec, start = stream.locate(pos)
         lo_seq, lo_st = np.round(sq, 3), _lib.round_decimals(st, 3)       # rnascan.py:273 on a float32 / on a Python float
-        tables.append({
-            "_rec": rec, "Sequence_ID": sb.id_column(rec), "Description.Seq": sb.description_column(rec), "Motif_ID.Seq": a,
-            "Start": start + 1, "End": start + m, "Sequence.Seq": sb.windows(pos, m), "LogOdds.Seq": lo_seq,
-            "Description.Struct": tb.description_column(rec), "Motif_ID.Struct": b, "Sequence.Struct": tb.windows(pos, m),
-            "LogOdds.Struct": lo_st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + lo_st})
+        return {"_rec": rec, "Sequence_ID": sb.id_column(rec), "Description.Seq": sb.description_column(rec), "Motif_ID.Seq": seq_ids,
+                "Start": start + 1, "End": start + m, "Sequence.Seq": sb.windows(pos, m), "LogOdds.Seq": lo_seq,
+                "Description.Struct": tb.description_column(rec), "Motif_ID.Struct": struct_ids, "Sequence.Struct": tb.windows(pos, m),
+                "LogOdds.Struct": lo_st, "LogOdds.SeqStruct": lo_seq.astype(np.float64) + lo_st}
+
+    by_width = {}
+    for a, b in pairs_m:
+        by_width.setdefault(seq_pssm[a].length, []).append((a, b))
+    for m, group in by_width.items():
+        if len(group) > 1 and np.isfinite(thr) and m <= LIBRARY_MAX_M and hasattr(engine, "library_hits_letters"):
+            # two libraries (RNAcompete-S style): every pair of this width in ONE pass (k_library over the sequences, the
+            # structure letters of its survivors); (position, pair index) order = (record, Start, Motif_ID.Seq, Motif_ID.Struct)
+            T = np.stack([seq_pssm[a].letter_table(pack.RNA_LETTERS) for a, _ in group])
+            S = np.stack([struct_pssm[b].letter_table(fasta.STRUCT) for _, b in group])
+            pos, mo, sq, st = engine.library_hits_letters(stream, T, S, thr, thr)
+            tables.append(rows(pos, sq, st, m, table.Indexed([a for a, _ in group], mo), table.Indexed([b for _, b in group], mo)))
+            continue
+        for a, b in group:
+            tab_seq = seq_pssm[a].letter_table(pack.RNA_LETTERS)
+            tab_st = struct_pssm[b].letter_table(fasta.STRUCT)
+            if np.isneginf(thr) or not hasattr(engine, "hits_pair"):
+                # every window with two finite scores is a row: all scores of both sides, the same strict `>` on the host
+                sq, _ = engine.scan(stream, tab_seq, None)
+                st = engine.scan_letters_f64(pack.Stream(tb.codes, None, tb.offsets, tb.lengths), tab_st)
+                pos = np.flatnonzero(stream.window_mask(m) & (sq.astype(np.float64) > thr) & (st > thr))
+                sq, st = sq[pos], st[pos]
+            else:
+                pos, sq, st = engine.hits_pair(stream, tab_seq, tab_st, thr, thr)
+            tables.append(rows(pos, sq, st, m, a, b))
     return _finish(tables, COMBINED_COLUMNS, ["Start", "Motif_ID.Seq", "Motif_ID.Struct"], columns)
 
 

@@ -203,3 +203,89 @@ def test_letter_libraries_through_the_device_entry_point(ctx, oracle):
             pos, mot, _, st = ctx.library_hits_letters_host(lib, b.codes, None, None, tt)
         assert got == sorted(zip(pos.tolist(), mot.tolist(), st.tolist()))
         lib.close()
+
+
+# ---- the CLI: `-q struct_library structs.fa` and `-p seq_library -q struct_library seqs.fa structs.fa` ---------------------
+def _letter_libraries(tmp_path, n_pairs=21, seed=9):
+    """two multi-PFM libraries (pfmutil.py:89-133) that share motif ids, mixed widths up to 32, + one structure PFM too wide
+    for the library kernel (scanned on its own) and one without a partner; FASTA pair with the same records"""
+    from test_gpu_letters8 import _fasta_pair
+    from test_scanner_cpu import _write_multi_pfm
+    rng = np.random.default_rng(seed)
+    seq_m, st_m = [], []
+    for k in range(n_pairs):
+        w = int(rng.choice([5, 8, 8, 12, 12, 17, 32]))
+        seq_m.append(("RBP%02d" % k, list("ACGU"), rng.dirichlet(np.full(4, 0.5), size=w)))
+        st_m.append(("RBP%02d" % k, list("EHTBLRM"), rng.dirichlet(np.full(7, 0.5), size=w)))
+    seq_m.append(("WIDE", list("ACGU"), rng.dirichlet(np.full(4, 0.5), size=40)))
+    st_m.append(("WIDE", list("EHTBLRM"), rng.dirichlet(np.full(7, 0.5), size=40)))
+    st_m.append(("STRUCT_ONLY", list("EHTBLRM"), rng.dirichlet(np.full(7, 0.5), size=8)))
+    lib_s, lib_t = str(tmp_path / "seq_lib.pfm"), str(tmp_path / "struct_lib.pfm")
+    _write_multi_pfm(lib_s, seq_m)
+    _write_multi_pfm(lib_t, st_m)
+    _fasta_pair(tmp_path / "s.fa", tmp_path / "t.fa", [int(x) for x in rng.integers(0, 1500, size=70)] + [4, 5, 31, 32, 33, 40], rng)
+    return lib_s, lib_t, str(tmp_path / "s.fa"), str(tmp_path / "t.fa")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from rnascan_amd import scanner
+    e = scanner.HipEngine(0)
+    yield e
+    e.close()
+
+
+def _run(argv, engine):
+    import io
+    from rnascan_amd import cli
+    out = io.StringIO()
+    cli.main(argv, engine=engine, out=out)
+    return out.getvalue()
+
+
+def _assert_same_table(got, want, what):
+    """byte equality, reported as the first differing line (pytest's own diff of two multi-megabyte strings takes minutes)"""
+    if got == want:
+        return
+    g, w = got.split("\n"), want.split("\n")
+    for i in range(max(len(g), len(w))):
+        a, b = (g[i] if i < len(g) else "<end>"), (w[i] if i < len(w) else "<end>")
+        if a != b:
+            raise AssertionError("%s: %d / %d lines, first difference at line %d:\n got  %s\n want %s" % (what, len(g), len(w), i, a, b))
+
+
+def test_cli_structure_letter_library_equals_the_per_motif_run(engine, tmp_path, monkeypatch):
+    """`rnascan -q struct_library structs.fa`: the one-pass library kernel prints the bytes of the per-motif run (the
+    oracle-backed engine has no library entry point: its scan_records loops over the motifs, as the reference would)"""
+    from engines import OracleEngine
+    from rnascan_amd import scanner
+    _, lib_t, _, t_fa = _letter_libraries(tmp_path)
+    calls = []
+    real = scanner.HipEngine.library_hits_letters
+    monkeypatch.setattr(scanner.HipEngine, "library_hits_letters", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+    for extra in (["-m", "1.5"], ["-m", "-2", "-C", "0.01"], []):
+        argv = ["-q", lib_t, "-u"] + extra + [t_fa]
+        got, want = _run(argv, engine), _run(argv, OracleEngine())
+        _assert_same_table(got, want, extra)
+    assert got.count("\n") > 20 and len(calls) >= 3 * 5          # one library launch per width (5, 8, 12, 17, 32), not per motif
+    monkeypatch.setenv("RNASCAN_BATCH_POSITIONS", "600")          # several batches: same bytes
+    _assert_same_table(_run(["-q", lib_t, "-u", "-m", "1.5", t_fa], engine), _run(["-q", lib_t, "-u", "-m", "1.5", t_fa], OracleEngine()), "batches")
+
+
+def test_cli_two_fasta_libraries_equal_the_per_pair_run(engine, tmp_path, monkeypatch):
+    """`rnascan -p seq_library -q struct_library seqs.fa structs.fa`: every pair of a width in ONE launch, same bytes as the
+    per-pair run (scanner.pair_motifs: two libraries pair by motif id; the reference never holds more than one motif per
+    side, rnascan.py:262)"""
+    from engines import OracleEngine
+    from rnascan_amd import scanner
+    lib_s, lib_t, s_fa, t_fa = _letter_libraries(tmp_path)
+    calls = []
+    real = scanner.HipEngine.library_hits_letters
+    monkeypatch.setattr(scanner.HipEngine, "library_hits_letters", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+    for extra in (["-m", "-1"], ["-m", "0.5", "-C", "0.01"], []):
+        argv = ["-p", lib_s, "-q", lib_t, "-u"] + extra + [s_fa, t_fa]
+        got, want = _run(argv, engine), _run(argv, OracleEngine())
+        _assert_same_table(got, want, extra)
+        if extra == ["-m", "-1"]:
+            assert got.count("\n") > 20
+    assert len(calls) >= 3 * 5
