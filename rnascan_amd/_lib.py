@@ -722,6 +722,15 @@ class Context(object):
     def library(self, letter_tables, struct_pssms=None, struct_letters=None):
         return Library(self, letter_tables, struct_pssms, struct_letters)
 
+    def library_hits_letters_dev(self, lib, d_codes, d_codes2, n_pos, thr_seq, thr_struct, capacity,
+                                 d_hit_pos, d_hit_motif, d_hit_seq, d_hit_struct, d_hit_count, stream=None):
+        """LETTER library on device-resident code streams (d_codes2 None for a structure-letter library): asynchronous on
+        ``stream``; hits unordered, *d_hit_count = total (above capacity = incomplete)"""
+        ts, tt = lib.thresholds(thr_seq, thr_struct)
+        self._check(self._L.pfmscan_library_hits_letters_dev(self._h, lib._h, _ptr(d_codes), _ptr(d_codes2), int(n_pos), _ptr(ts), _ptr(tt),
+                                                             int(capacity), _ptr(d_hit_pos), _ptr(d_hit_motif), _ptr(d_hit_seq),
+                                                             _ptr(d_hit_struct), _ptr(d_hit_count), _ptr(stream)))
+
     def library_hits_letters_host(self, lib, codes, codes2=None, thr_seq=None, thr_struct=None, capacity=None):
         """hits of a LETTER library (Library(struct_letters=...)): ``codes`` is the 8-code stream of a structure-letter library,
         or the sequence codes of a two-FASTA library whose structure strings are ``codes2`` -> as library_hits_staged"""
