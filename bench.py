@@ -350,6 +350,40 @@ def main():
     if args.mode != "scores":
         n_hits = host_hits[0] if args.from_host else int(hit_count.item())
 
+    # ---- the same kernel on arrays from the DEFAULT allocator (what callers that do not use pfmscan_place_alloc get), after
+    # the timed region and under the same clocks: the line carries both, so the kernel's share and the placement's share of
+    # the headline can be told apart in one record
+    default_alloc = None
+    if placed is not None and args.mode == "scores" and not is_lib and not os.environ.get("PFMSCAN_BENCH_NO_DEFAULT_ALLOC"):
+        try:
+            d_codes, d_prof = codes.clone(), (None if seq_only else profile.clone())
+            d_seq, d_st = torch.zeros(n_pos, dtype=torch.float32, device=dev), (None if seq_only else torch.zeros(n_pos, dtype=torch.float64, device=dev))
+
+            def step_default():
+                ctx.scan_dev(motif, d_codes.data_ptr(), None if seq_only else d_prof.data_ptr(), _lib.PROFILE_NONE if seq_only else ptype, n_pos,
+                             d_seq.data_ptr(), None if seq_only else d_st.data_ptr(), stream)
+            for _ in range(5):
+                step_default()
+            torch.cuda.synchronize()
+            dev_evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            dev_evs[0].record()
+            for i in range(args.steps):
+                step_default()
+                dev_evs[i + 1].record()
+            torch.cuda.synchronize()
+            d_ms = np.array([dev_evs[i].elapsed_time(dev_evs[i + 1]) for i in range(args.steps)])
+            default_alloc = {"kernel_ms": float(dev_evs[0].elapsed_time(dev_evs[args.steps]) / args.steps),
+                             "kernel_ms_median": float(np.median(d_ms)), "kernel_ms_min": float(d_ms.min())}
+            del d_codes, d_prof, d_seq, d_st
+            torch.cuda.empty_cache()
+        except Exception as exc:                                  # e.g. not enough memory for a second resident set
+            default_alloc = {"error": str(exc)}
+
+    # ---- this rank's memory floor (tools/hbm_mixed on THIS rank's GPU): a slow rank and a badly placed one look different
+    rank_floor = None
+    if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32" and not args.from_host:
+        rank_floor = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned", device=local_rank)
+
     # ---- per-rank parity sample (multi-GPU runs): a few records of THIS rank's shard against the CPU oracle
     rank_parity = None
     if dist is not None and args.mode == "scores" and not seq_only and not args.no_cpu_baseline:
@@ -368,14 +402,18 @@ def main():
         vs = np.isfinite(ref_st) & (np.abs(ref_st) < 1e9)
         rank_parity = bool(ok_seq and float(np.abs(got_st[vs] - ref_st[vs]).max()) <= 1e-6)
 
-    rank_ms, rank_ok, rank_hits = [kernel_ms], [rank_parity], [n_hits]
+    rank_ms, rank_ok, rank_hits, rank_detail = [kernel_ms], [rank_parity], [n_hits], {}
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
         box = [None] * world
-        dist.all_gather_object(box, (kernel_ms_rank, rank_parity, n_hits))
+        dist.all_gather_object(box, (kernel_ms_rank, rank_parity, n_hits, float(np.median(step_ms)), float(step_ms.min()), placement.get("note"),
+                                     default_alloc, rank_floor))
         rank_ms, rank_ok, rank_hits = [b[0] for b in box], [b[1] for b in box], [b[2] for b in box]
+        rank_detail = {"kernel_ms_median": [b[3] for b in box], "kernel_ms_min": [b[4] for b in box], "placement_note": [b[5] for b in box],
+                       "kernel_ms_default_allocator": [None if not b[6] else b[6].get("kernel_ms") for b in box],
+                       "mixed_read_write_floor_ms": [None if not b[7] else b[7]["ms"] for b in box]}
 
     result = None
     if rank == 0:
@@ -455,7 +493,7 @@ def main():
         if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32":
             # the same byte mix (29 B in + 12 B out per position) moved by a program that scores nothing
             # (tools/hbm_mixed.hip, measured on this chip in round 4): what the memory system gives this access pattern
-            live = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned") if (rank == 0 and world == 1) else None
+            live = rank_floor
             floor = pmc_entry("c3_mixed_floor")
             if live is not None:
                 result["roofline"]["mixed_read_write_floor"] = dict(live, frac_of_floor=live["ms"] / kernel_ms, kernel_over_floor=kernel_ms / live["ms"])
@@ -466,9 +504,16 @@ def main():
                                                        "(tools/hbm_mixed is not built here): boxes of the pool differ by up to 10 % on it"}
         if traffic is not None:
             result["roofline"]["traffic_pmc_round"] = pmc_entry("c2" if seq_only else "c3").get("round")
+        if default_alloc is not None:
+            result["roofline"]["kernel_ms_default_allocator"] = default_alloc.get("kernel_ms")
+            result["roofline"]["default_allocator"] = dict(default_alloc, frac=None if "kernel_ms" not in default_alloc else
+                                                           alg_bytes / (default_alloc["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                           note="the same kernel, the same data, arrays from torch's caching allocator (hipMalloc) instead of "
+                                                                "pfmscan_place_alloc; measured right after the timed region")
         if dist is not None:
-            result["per_rank"] = {"kernel_ms": rank_ms, "parity_sample_ok": rank_ok,
-                                  "note": "no 1 -> N curve is claimed by this line: value = all ranks' windows / max-over-ranks time"}
+            result["per_rank"] = dict({"kernel_ms": rank_ms, "parity_sample_ok": rank_ok,
+                                       "note": "no 1 -> N curve is claimed by this line: value = all ranks' windows / max-over-ranks time"},
+                                      **rank_detail)
         if args.from_host:
             h2d = args.records * (args.length + 1) * in_b
             result["metric"] = "END-TO-END " + result["metric"] + " from pageable host memory (upload + scan + sorted hits back)"

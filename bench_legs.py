@@ -128,7 +128,7 @@ def pmc_entry(workload):
     return {}
 
 
-def live_mixed_floor(records, length, placed=False):
+def live_mixed_floor(records, length, placed=False, device=0):
     """tools/hbm_mixed `quick` as a child process on the same GPU, right after the timed region: the fastest of its
     read+write forms is what THIS box's memory system gives the headline's byte mix (29 B in + 12 B out per position,
     nothing scored).  None when the tool is not built (rnascan_amd/build.py: build_floor_tool)."""
@@ -138,7 +138,11 @@ def live_mixed_floor(records, length, placed=False):
     if not os.access(exe, os.X_OK) or os.environ.get("PFMSCAN_BENCH_NO_FLOOR") or profiled:     # no child processes under a profiler
         return None
     try:
-        out = subprocess.run([exe, str(records), str(length), "quick"] + (["placed"] if placed else []), capture_output=True, text=True, timeout=120)
+        env = dict(os.environ)
+        vis = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+        env["HIP_VISIBLE_DEVICES"] = vis[device] if device < len(vis) else str(device)          # the child sees only this rank's GPU
+        out = subprocess.run([exe, str(records), str(length), "quick"] + (["placed"] if placed else []), capture_output=True, text=True,
+                             timeout=120, env=env)
     except (OSError, subprocess.TimeoutExpired):
         return None
     for ln in out.stdout.splitlines():

@@ -67,11 +67,12 @@ def getoptions(argv=None):
                            "NOTE: the reference run on Python >= 3.6 pairs them by POSITION (file order BEHLMRT against the "
                            "PFM's EHTBLRM, rnascan.py:300-307) and therefore prints different structure scores than this "
                            "default; '--pairing positional' reproduces those numbers exactly [%(default)s]"))
-    gpu.add_argument("--profile-dtype", choices=["auto", "float64", "float32"], default="auto",
-                     help=("device storage of averaged-structure profiles: float64 reproduces the reference's fp64 scores to "
-                           "~1e-14; float32 halves the HBM traffic at a storage error of at most 2^-24 x (sum over the PFM's "
-                           "rows of the largest finite |log-odds|); auto takes float32 when that bound is below 5e-7 for the "
-                           "structure PFM at hand, else float64, and says so on stderr [%(default)s]"))
+    gpu.add_argument("--profile-dtype", choices=["auto", "float64", "float32"], default="float64",
+                     help=("device storage of averaged-structure profiles: float64 reproduces the reference's fp64 scores (it "
+                           "prints them unrounded, rnascan.py:293-315) to ~1e-14; float32 halves the HBM traffic at a storage "
+                           "error of at most 2^-24 x (sum over the PFM's rows of the largest finite |log-odds|); auto takes "
+                           "float32 when that bound is below 5e-7 for the structure PFM at hand, else float64, and says so on "
+                           "stderr [%(default)s]"))
     args = parser.parse_args(argv)
     if not (args.pfm_seq or args.pfm_struct):
         parser.error("Must specify PFMs with -p and/or -q")
@@ -107,7 +108,7 @@ def profile_type(args, struct_pssm, stored=None):
     as they are whatever the PFM's bound says (nothing is rounded on the way, and widening them would change no score)"""
     got = getattr(args, "_profile_type", None)
     if got is None:
-        asked = getattr(args, "profile_dtype", "auto")
+        asked = getattr(args, "profile_dtype", "float64")
         if stored is not None and np.dtype(stored) == np.float32 and asked != "float32":
             args._profile_type = np.float32
             fasta.eprint("Averaged-structure profiles are stored as float32 on the device (the packed store holds float32 rows: "
@@ -115,7 +116,7 @@ def profile_type(args, struct_pssm, stored=None):
             return np.float32
         got, bound = scanner.pick_profile_dtype(asked, struct_pssm)
         args._profile_type = got
-        how = "as asked" if getattr(args, "profile_dtype", "auto") != "auto" else \
+        how = "as asked" if asked != "auto" else \
             ("worst-case storage error %.1e < %.0e" % (bound, scanner.FLOAT32_STORAGE_BUDGET) if got is np.float32 else
              "float32 storage could cost up to %.1e > %.0e" % (bound, scanner.FLOAT32_STORAGE_BUDGET))
         fasta.eprint("Averaged-structure profiles are stored as %s on the device (%s)" % (np.dtype(got).name, how))

@@ -178,7 +178,6 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
     if (letter_table && m <= 32) {
         mo->h_letters = new (std::nothrow) double[(size_t)m * 8];
         if (mo->h_letters) std::memcpy(mo->h_letters, letter_table, sizeof(double) * m * 8);
-        if (mo->h_letters && hipMalloc((void **)&mo->d_cred8, 8 * 16 * sizeof(uint32_t)) != hipSuccess) mo->d_cred8 = nullptr;
     }
     if (e == hipSuccess && letter_table) {
         // hits-mode prefilter table: only when the alphabet is the 4 codes 0..3 (columns 4..7 all NaN)
@@ -245,7 +244,6 @@ void pfmscan_motif_destroy(pfmscan_motif *mo)
     if (mo->d_pairs) (void)hipFree(mo->d_pairs);
     if (mo->d_struct) (void)hipFree(mo->d_struct);
     if (mo->d_quad) (void)hipFree(mo->d_quad);
-    if (mo->d_cred8) (void)hipFree(mo->d_cred8);
     delete[] mo->h_quadsum;
     delete[] mo->h_letters;
     delete mo;
@@ -282,7 +280,6 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.cred_cache = &mo->cred_cache;
     a.h_letters = mo->h_letters;
     a.cred8_cache = &mo->cred8_cache;
-    a.d_cred8 = mo->d_cred8;
     a.struct_pssm = mo->d_struct;
     a.m = mo->m;
     a.struct_finite = mo->struct_finite;

@@ -20,7 +20,6 @@ struct pfmscan_motif {
     mutable pfmscan::CredCache cred_cache;
     double *h_letters = nullptr;   // host copy of the letter table [m][8] (m <= 32): operand of k_letters_cred8's credits
     mutable pfmscan::Cred8Cache cred8_cache;
-    uint32_t *d_cred8 = nullptr;   // device: that kernel's packed credit table (rewritten when the threshold changes)
     double *d_struct = nullptr;    // [m][7]
     int m = 0;
     int struct_finite = 0;

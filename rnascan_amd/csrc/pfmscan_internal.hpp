@@ -21,7 +21,6 @@ struct Cred8Cache {
     double thr = __builtin_nan("");
     int mode = 0;                // 1: k_letters_cred8 with cr; 2: dense threshold -> the exact kernel; 3: no integer prefilter possible
     uint16_t cr[32 * 8];
-    bool on_device = false;      // the motif's device copy holds this table
 };
 
 struct ScanArgs {
@@ -44,8 +43,7 @@ struct ScanArgs {
     const uint8_t *codes2;       // two-FASTA combined scan fused into k_letters_cred: the second code stream (device) or null
     const double *letter_table2; // ... and its letter table [m][8] (device); hits then need seq > thr_seq AND letters2 > thr_struct
     const double *h_letters;     // HOST: the letter table [m][8] (operand of the single-letter credits of k_letters_cred8)
-    Cred8Cache *cred8_cache;     // HOST: owned by the motif
-    uint32_t *d_cred8;           // DEVICE: [8][16] dwords, the packed credit table of cred8_cache->thr, owned by the motif
+    Cred8Cache *cred8_cache;     // HOST: owned by the motif (the packed table itself travels with each launch)
     const double *struct_pssm;   // [m][7] device or null
     int m;
     int struct_finite;           // every struct_pssm cell finite -> fast path legal

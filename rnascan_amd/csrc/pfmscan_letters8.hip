@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "pfmscan_device.hpp"
@@ -43,7 +44,7 @@ struct Cred8Table {
 constexpr int Q8_CAP = 128;                            // hits a wave can park (12 bytes each)
 
 template <int NJ>
-__global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a)
+__global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const Cred8Table ct)
 {
     constexpr int W = 16;                              // windows per lane = one round per tile
     constexpr int LET_TILE = BLOCK * W;
@@ -78,9 +79,15 @@ __global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a)
     cs.fetch(a.codes, first, n_pos);
     // rows m .. are zeros: x + 0.0 == x for every x a sum that started at +0.0 can hold (never -0.0)
     for (int i = threadIdx.x; i < TROWS * 8; i += BLOCK) tbl[i] = i < m * 8 ? a.letter_table[i] : 0.0;
-    // the credit table comes from device memory (a.d_cred8, [8][16] dwords): as a by-value kernel argument its per-lane
-    // indexing kept all 128 dwords in SGPRs and the widest instantiation spilled 57 of them to VGPR lanes
-    for (int i = threadIdx.x; i < 8 * EDW; i += BLOCK) ctab[i] = (i % EDW) < NJ ? a.d_cred8[(i / EDW) * 16 + (i % EDW)] : 0u;
+    // The credit table travels WITH the launch (a by-value argument: no device copy to keep in step with the threshold, no
+    // synchronisation when it changes) and is read straight from the kernarg segment with per-lane vector loads: indexed
+    // as `ct.d[..][..]` hipcc kept all 128 dwords in SGPRs and the widest instantiation spilled 57 of them to VGPR lanes.
+    static_assert(sizeof(ScanArgs) % alignof(Cred8Table) == 0, "ct follows a in the kernarg segment");
+    (void)ct;
+    typedef const __attribute__((address_space(4))) unsigned char *karg_ptr;
+    const __attribute__((address_space(4))) uint32_t *ktab =
+        (const __attribute__((address_space(4))) uint32_t *)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ScanArgs));
+    for (int i = threadIdx.x; i < 8 * EDW; i += BLOCK) ctab[i] = (i % EDW) < NJ ? ktab[(i / EDW) * 16 + (i % EDW)] : 0u;
     if (threadIdx.x < NWAVE) q_n[threadIdx.x] = 0;
     cs.park(cbuf[0]);
     if (ntile > 1 && first + LET_TILE < n_pos) cs.fetch(a.codes, first + LET_TILE, n_pos);
@@ -335,41 +342,38 @@ static int walk_tiles8(int64_t ntiles, const Tuning &t)
 
 bool launch_letters_cred8(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
-    if (!(a.hits && a.f64_hits && a.h_letters && a.cred8_cache && a.d_cred8 && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
+    if (!(a.hits && a.f64_hits && a.h_letters && a.cred8_cache && a.m <= 32 && t.credits && std::isfinite(a.thr_seq))) return false;
     Cred8Cache *cc = a.cred8_cache;
-    if (!(cc->thr == a.thr_seq) || cc->mode == 0) {
-        build_cred8(a.h_letters, a.m, a.thr_seq, cc);
-        cc->on_device = false;
+    Cred8Table ct;
+    int mode;
+    {
+        // the motif keeps what the last threshold gave (credits + survivor prediction: a millisecond of host work); two host
+        // threads scanning with the same motif take turns here, and each launch carries its own copy of the table
+        static std::mutex cred8_mu;                    // (one lock for all motifs: pfmscan_motif objects are copied by value in places)
+        std::lock_guard<std::mutex> lock(cred8_mu);
+        if (!(cc->thr == a.thr_seq) || cc->mode == 0) build_cred8(a.h_letters, a.m, a.thr_seq, cc);
+        mode = cc->mode;
+        std::memset(&ct, 0, sizeof(ct));
+        if (mode == 1)
+            for (int c = 0; c < 8; ++c)
+                for (int j = 0; j < a.m; ++j) ct.d[c][j >> 1] |= (uint32_t)cc->cr[j * 8 + c] << (16 * (j & 1));
     }
-    if (cc->mode != 1) return false;                   // -> the exact kernel (k_letters<..., double, HITS>)
+    if (mode != 1) return false;                       // -> the exact kernel (k_letters<..., double, HITS>)
     int nj = (a.m + 1) / 2;
     if (const char *v = std::getenv("PFMSCAN_CRED8_NJ")) nj = std::max(nj, std::atoi(v));   // tests: a wider bucket than the PFM needs
-    if (!cc->on_device) {
-        // the table of the call's threshold lives on the device with the motif and is rewritten only when the threshold
-        // changes; another launch (on any stream) may still read the old one: threshold changes are rare, wait for the device
-        Cred8Table ct;
-        std::memset(&ct, 0, sizeof(ct));
-        for (int c = 0; c < 8; ++c)
-            for (int j = 0; j < a.m; ++j) ct.d[c][j >> 1] |= (uint32_t)cc->cr[j * 8 + c] << (16 * (j & 1));
-        *err = hipDeviceSynchronize();
-        if (*err != hipSuccess) return true;
-        *err = hipMemcpy(a.d_cred8, &ct, sizeof(ct), hipMemcpyHostToDevice);
-        if (*err != hipSuccess) return true;
-        cc->on_device = true;
-    }
     constexpr int TILE = BLOCK * 16;
     ScanArgs b = a;
     const int64_t ntiles = (a.n_pos + TILE - 1) / TILE;
     b.tiles_per_block = walk_tiles8(ntiles, t);
     if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
     const unsigned g = (unsigned)((ntiles + b.tiles_per_block - 1) / b.tiles_per_block);
-    if (nj <= 2) hipLaunchKernelGGL((k_letters_cred8<2>), dim3(g), dim3(BLOCK), 0, stream, b);
-    else if (nj <= 4) hipLaunchKernelGGL((k_letters_cred8<4>), dim3(g), dim3(BLOCK), 0, stream, b);
-    else if (nj <= 6) hipLaunchKernelGGL((k_letters_cred8<6>), dim3(g), dim3(BLOCK), 0, stream, b);
-    else if (nj <= 8) hipLaunchKernelGGL((k_letters_cred8<8>), dim3(g), dim3(BLOCK), 0, stream, b);
-    else if (nj <= 10) hipLaunchKernelGGL((k_letters_cred8<10>), dim3(g), dim3(BLOCK), 0, stream, b);     // the reference's example PFMs are 18 wide
-    else if (nj <= 12) hipLaunchKernelGGL((k_letters_cred8<12>), dim3(g), dim3(BLOCK), 0, stream, b);
-    else hipLaunchKernelGGL((k_letters_cred8<16>), dim3(g), dim3(BLOCK), 0, stream, b);
+    if (nj <= 2) hipLaunchKernelGGL((k_letters_cred8<2>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+    else if (nj <= 4) hipLaunchKernelGGL((k_letters_cred8<4>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+    else if (nj <= 6) hipLaunchKernelGGL((k_letters_cred8<6>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+    else if (nj <= 8) hipLaunchKernelGGL((k_letters_cred8<8>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+    else if (nj <= 10) hipLaunchKernelGGL((k_letters_cred8<10>), dim3(g), dim3(BLOCK), 0, stream, b, ct);     // the reference's example PFMs are 18 wide
+    else if (nj <= 12) hipLaunchKernelGGL((k_letters_cred8<12>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
+    else hipLaunchKernelGGL((k_letters_cred8<16>), dim3(g), dim3(BLOCK), 0, stream, b, ct);
     *err = hipGetLastError();
     return true;
 }

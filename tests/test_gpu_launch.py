@@ -35,6 +35,14 @@ def test_bench_gpus_2_rehearsal_reports_two_ranks():
     assert res["n_gpus"] == 2 and res["value"] > 0 and "dry_run" not in res
     assert len(res["per_rank"]["kernel_ms"]) == 2 and all(ms > 0 for ms in res["per_rank"]["kernel_ms"])
     assert res["per_rank"]["parity_sample_ok"] == [True, True]
+    # what tells a slow rank from a badly placed one without a second run: every rank's placement line, spread of its launches,
+    # the same kernel on default-allocator arrays and its own memory floor
+    pr = res["per_rank"]
+    for key in ("kernel_ms_median", "kernel_ms_min", "placement_note", "kernel_ms_default_allocator", "mixed_read_write_floor_ms"):
+        assert len(pr[key]) == 2, key
+    assert all(v > 0 for v in pr["kernel_ms_median"] + pr["kernel_ms_min"] + pr["kernel_ms_default_allocator"])
+    assert all(isinstance(n, str) and n for n in pr["placement_note"])
+    assert res["roofline"]["kernel_ms_default_allocator"] > 0
     # whole-job value: both ranks' windows over the slower rank's time
     assert res["value"] == pytest.approx(2 * 4000 * (3000 - 12 + 1) * 3 / (res["ms_per_step"] * 3e-3), rel=1e-6)
 
