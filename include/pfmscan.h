@@ -543,12 +543,26 @@ int pfmscan_time_scan_dev(pfmscan_ctx *ctx, const pfmscan_motif *motif,
  * through the HIP virtual memory API, measures which chunks disturb each other, gives every array the chunks that disturb the
  * chunks the other arrays use at the same fraction of the pass least, and returns ptrs[r] (contiguous, 2 MB aligned, contents
  * undefined, usable like any device pointer with every *_dev entry point).  PFMSCAN_PLACE_PLAIN in `flags` (or in the
- * environment) skips the measurement.  pfmscan_place_free takes ptrs[0] of a set and frees the whole set after a device
- * synchronise; pfmscan_ctx_destroy frees what is left.  pfmscan_place_note: one line about the last allocation (candidates,
- * measured pair times, weighted disturbance chosen / driver order).  Results of scans never depend on placement. */
+ * environment) skips the measurement.  pfmscan_place_note: one line about the last allocation (candidates, measured pair
+ * times, weighted disturbance chosen / driver order).  Results of scans never depend on placement.
+ *
+ * COST IN ADDRESS SPACE, AND WHAT pfmscan_place_free DOES.  On ROCm 7.2 an address range that was unmapped, freed and handed
+ * out again for other physical memory read back other bytes than were written (profiles/r4/placement/
+ * ab_ranges_reused_corrupt.txt; rnascan_amd/csrc/pfmscan_place.hip has the analysis), so NO range this allocator reserves is
+ * ever given back while the context lives:
+ *   * a measured allocation reserves (candidates + needed chunks) x chunk size of address space -- ~60 GB for the headline
+ *     scan's 12.3 GB (24 candidate chunks of 2 GB + the arrays), at most ~140 GB -- a plain one only the arrays' size;
+ *   * pfmscan_place_free(ptrs[0]) synchronises the device and RETIRES the set: it stays mapped, memory included, and the
+ *     next pfmscan_place_alloc of the same sizes and flags returns it as it is (no new range, no measurement: an
+ *     allocate / scan / free loop costs nothing after its first round).  The two most recently retired sets keep their
+ *     memory; an older one is unmapped and its memory released at once (its ranges stay reserved).  pfmscan_place_trim
+ *     releases the memory of every retired set now.  pfmscan_ctx_destroy releases all memory;
+ *   * a context may reserve 16 TB in all (an eighth of the 47-bit user address space: ~270 measured allocations of the
+ *     headline's size with DIFFERENT sizes each time); beyond that pfmscan_place_alloc returns PFMSCAN_E_OOM and says why. */
 #define PFMSCAN_PLACE_PLAIN 1
 int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, void **ptrs, int flags);
 int pfmscan_place_free(pfmscan_ctx *ctx, void *first_array);
+int pfmscan_place_trim(pfmscan_ctx *ctx);
 const char *pfmscan_place_note(const pfmscan_ctx *ctx);
 
 #ifdef __cplusplus

@@ -39,7 +39,7 @@ SYMBOLS = [
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
     "pfmscan_hits_pair_dev", "pfmscan_stage_codes2", "pfmscan_hits_pair_staged", "pfmscan_hits_pair_host", "pfmscan_round_decimals",
     "pfmscan_set_upload_mode", "pfmscan_upload_source_file", "pfmscan_upload_source_file_checked", "pfmscan_fasta_lone_cr", "pfmscan_count_bytes", "pfmscan_fasta_index", "pfmscan_fasta_ids", "pfmscan_gather_spans", "pfmscan_fasta_encode", "pfmscan_tsv_format", "pfmscan_profile_parse", "pfmscan_tsv_number",
-    "pfmscan_place_alloc", "pfmscan_place_free", "pfmscan_place_note",
+    "pfmscan_place_alloc", "pfmscan_place_free", "pfmscan_place_note", "pfmscan_place_trim",
 ]
 TSV_CONST, TSV_I64, TSV_F32, TSV_F64, TSV_INDEXED, TSV_FIXED, TSV_WINDOW, TSV_SPAN = range(8)
 
@@ -140,6 +140,7 @@ def load():
     L.pfmscan_count_bytes.argtypes = [vp, i64, vp, i32]
     L.pfmscan_place_alloc.argtypes = [vp, i32, vp, vp, i32]
     L.pfmscan_place_free.argtypes = [vp, vp]
+    L.pfmscan_place_trim.argtypes = [vp]
     L.pfmscan_place_note.argtypes = [vp]
     L.pfmscan_place_note.restype = ctypes.c_char_p
     L.pfmscan_fasta_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(i64), i32]
@@ -456,6 +457,10 @@ class Context(object):
 
     def place_note(self):
         return (self._L.pfmscan_place_note(self._h) or b"").decode()
+
+    def place_trim(self):
+        """give back the memory of the sets pfmscan_place_free keeps for reuse (include/pfmscan.h)"""
+        self._check(self._L.pfmscan_place_trim(self._h))
 
     # -- PSSM operands ----------------------------------------------------------
     def motif(self, letter_table=None, struct_pssm=None):

@@ -72,6 +72,8 @@ struct pfmscan_ctx {
     bool two_phase_hot = false;
     // pfmscan_place.hip: sets of arrays placed together (PlaceSet *), and a line about the last allocation
     std::vector<void *> place_sets;
+    std::vector<void *> place_retired;        // freed sets kept mapped for the next request of the same sizes
+    size_t place_va_reserved = 0;             // address space reserved so far (never given back while the context lives)
     std::string place_note;
 };
 

@@ -37,7 +37,16 @@ struct PlaceSet {
     };
     std::vector<Arr> arrays;
     size_t chunk = 0;
+    std::vector<int64_t> bytes;       // the request it was made for (a later request of the same sizes gets a retired set back)
+    bool plain = false;
+    std::string note;
 };
+
+// Address space pfmscan_place_alloc may reserve per context over its whole life (ranges are never reused, see below): an
+// eighth of the 47-bit user space.  A measured allocation of the headline's size reserves ~60 GB (48 GB probe window + the
+// arrays): ~270 of them.  Same-sized requests after a pfmscan_place_free cost nothing (the retired set is handed out again).
+constexpr size_t PLACE_VA_BUDGET = (size_t)16 << 40;
+constexpr size_t PLACE_RETIRED_MAX = 2;   // retired sets kept WITH their memory for reuse; older ones give their memory back
 
 // n16 vectors to x and n16 vectors to y: two sequential nontemporal write streams (the probe of pfmscan_place_alloc)
 __global__ __launch_bounds__(BLOCK) void k_place_probe(u32x4 *__restrict__ x, u32x4 *__restrict__ y, size_t n16)
@@ -75,18 +84,28 @@ void place_release_all(pfmscan_ctx *ctx)
 {
     for (void *p : ctx->place_sets) release_set(static_cast<PlaceSet *>(p));
     ctx->place_sets.clear();
+    for (void *p : ctx->place_retired) release_set(static_cast<PlaceSet *>(p));
+    ctx->place_retired.clear();
 }
 
 }  // namespace pfmscan
 
 using namespace pfmscan;
 
-// ADDRESS RANGES ARE NEVER REUSED.  On ROCm 7.2 / MI355X a virtual address range that was unmapped, freed and handed out again
-// (by hipMemAddressReserve, and nothing says hipMalloc could not get it too) still translates to the OLD physical pages for a
-// while: arrays allocated after a pfmscan_place_free read back other bytes than were written (tools/placement_ab.py caught it:
-// "inputs intact right after the copy: False" from the second allocation on, gone when the ranges are kept; a 4 s pause did not
-// help).  So every range this file maps stays reserved until the process ends -- address space, not memory: the physical
-// chunks are released, and 47 bits of address space hold ~800 sets the size of the headline scan's.
+// ADDRESS RANGES ARE NEVER REUSED.  On ROCm 7.2 / MI355X a virtual address range that was unmapped, given back
+// (hipMemAddressFree) and handed out again by hipMemAddressReserve for OTHER physical chunks read back other bytes than were
+// written: profiles/r4/placement/ab_ranges_reused_corrupt.txt -- "inputs intact right after the copy: False" from the THIRD
+// allocation of the process on (the first that can be given a range an earlier set had mapped and freed), 30-98 % of the
+// scores wrong from there on, and gone (ab_ranges_kept.txt) when the ONLY change is that ranges stay reserved.  Not a missing
+// synchronisation or access grant: the free path of that build already ran hipDeviceSynchronize() before hipMemUnmap, every new
+// mapping gets its hipMemSetAccess, and a 4 s pause changed nothing.  What the record cannot tell is which layer keeps the old
+// translation; it is treated as a driver limitation and avoided:
+//   * every range this file maps stays reserved until the context is destroyed (address space, not memory);
+//   * a freed set is RETIRED, not unmapped: the next request of the same sizes gets it back as it is (no new range, no
+//     new measurement) -- a loop of allocate / scan / free does not grow;  the last PLACE_RETIRED_MAX retired sets keep
+//     their memory (pfmscan_place_trim gives it back), older ones are unmapped and their memory released at once;
+//   * the address space reserved per context is bounded (PLACE_VA_BUDGET): beyond it pfmscan_place_alloc fails with
+//     PFMSCAN_E_OOM instead of eating the process's address space.
 extern "C" {
 
 int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, void **ptrs, int flags)
@@ -97,6 +116,18 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
         if (bytes[r] <= 0) return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_place_alloc: array sizes must be positive");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     bool plain = (flags & PFMSCAN_PLACE_PLAIN) || std::getenv("PFMSCAN_PLACE_PLAIN");
+    // a retired set of the same request: handed out again as it is
+    for (size_t i = 0; i < ctx->place_retired.size(); ++i) {
+        PlaceSet *s = static_cast<PlaceSet *>(ctx->place_retired[i]);
+        if (s->plain == plain && (int)s->bytes.size() == n_arrays && std::equal(s->bytes.begin(), s->bytes.end(), bytes) && !s->arrays.empty() &&
+            !s->arrays[0].handles.empty()) {
+            for (int r = 0; r < n_arrays; ++r) ptrs[r] = s->arrays[r].va;
+            ctx->place_retired.erase(ctx->place_retired.begin() + (long)i);
+            ctx->place_sets.push_back(s);
+            ctx->place_note = s->note + "; the set of an earlier pfmscan_place_free handed out again (same sizes: no new address range, no new measurement)";
+            return PFMSCAN_OK;
+        }
+    }
     size_t chunk = (size_t)2048 << 20;
     int64_t largest = 0;
     for (int r = 0; r < n_arrays; ++r) largest = std::max(largest, bytes[r]);
@@ -131,6 +162,11 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
     if (const char *v = std::getenv("PFMSCAN_PLACE_CANDIDATES")) cand = std::max(total, std::atoi(v));
     cand = std::min(cand, 64);
     cand = std::max(total, std::min(cand, (int)((double)free_b * 0.85 / (double)chunk)));
+    size_t budget = PLACE_VA_BUDGET;
+    if (const char *v = std::getenv("PFMSCAN_PLACE_VA_BUDGET_GB")) budget = (size_t)std::max(0, std::atoi(v)) << 30;      // tests
+    if (ctx->place_va_reserved + (size_t)(cand + total) * chunk > budget)
+        return fail(ctx, PFMSCAN_E_OOM, "pfmscan_place_alloc: the address-space budget of this context is used up (" +
+                                           std::to_string(ctx->place_va_reserved >> 30) + " GB reserved by earlier sets; ranges are never reused: include/pfmscan.h)");
 
     // candidates: chunks of physical memory, mapped side by side into a window for the measurement
     std::vector<hipMemGenericAllocationHandle_t> h;
@@ -196,6 +232,7 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
     bool tuned = false;
     if (!plain && n > total) {
         hipError_t e = hipMemAddressReserve((void **)&window, (size_t)cand * chunk, 0, nullptr, 0);
+        if (e == hipSuccess) ctx->place_va_reserved += (size_t)cand * chunk;
         if (e == hipSuccess) {
             for (int i = 0; i < n && e == hipSuccess; ++i) e = hipMemMap(window + (size_t)i * chunk, chunk, 0, h[i], 0);
             if (e == hipSuccess) e = hipMemSetAccess(window, (size_t)n * chunk, &acc, 1);
@@ -358,6 +395,8 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
         return fail(ctx, PFMSCAN_E_OOM, "out of host memory");
     }
     set->chunk = chunk;
+    set->bytes.assign(bytes, bytes + n_arrays);
+    set->plain = (flags & PFMSCAN_PLACE_PLAIN) || std::getenv("PFMSCAN_PLACE_PLAIN");
     set->arrays.resize(n_arrays);
     std::vector<char> taken(n, 0);
     hipError_t e = hipSuccess;
@@ -369,6 +408,7 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
             arr.va = nullptr;
             break;
         }
+        ctx->place_va_reserved += arr.va_bytes;
         for (int a = 0; a < total && e == hipSuccess; ++a)
             if (need[a].r == r) {
                 e = hipMemMap(arr.va + (size_t)need[a].k * chunk, chunk, 0, h[order[a]], 0);
@@ -399,6 +439,7 @@ int pfmscan_place_alloc(pfmscan_ctx *ctx, int n_arrays, const int64_t *bytes, vo
         std::snprintf(line, sizeof(line), "%d arrays in %d chunks of %zu MB; NOT tuned: chunks in driver order%s", n_arrays, total, chunk >> 20,
                       plain ? "" : " (no spare chunks to choose from)");
     ctx->place_note = std::string(line) + (note.empty() ? "" : "; " + note);
+    set->note = ctx->place_note;
     return PFMSCAN_OK;
 }
 
@@ -410,12 +451,28 @@ int pfmscan_place_free(pfmscan_ctx *ctx, void *first_array)
         if (!s->arrays.empty() && s->arrays[0].va == first_array) {
             HIP_TRY(ctx, hipSetDevice(ctx->device));
             HIP_TRY(ctx, hipDeviceSynchronize());
-            release_set(s);
             ctx->place_sets.erase(ctx->place_sets.begin() + (long)i);
+            // retired, not unmapped: the next request of the same sizes gets it back as it is.  Only the last few retired
+            // sets keep their memory; an older one is unmapped and its memory released (its address ranges stay reserved).
+            ctx->place_retired.push_back(s);
+            while (ctx->place_retired.size() > PLACE_RETIRED_MAX) {
+                release_set(static_cast<PlaceSet *>(ctx->place_retired.front()));
+                ctx->place_retired.erase(ctx->place_retired.begin());
+            }
             return PFMSCAN_OK;
         }
     }
     return fail(ctx, PFMSCAN_E_BADARG, "pfmscan_place_free: not the first array of a set of pfmscan_place_alloc");
+}
+
+int pfmscan_place_trim(pfmscan_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, PFMSCAN_E_BADARG, "pfmscan_place_trim: null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    for (void *p : ctx->place_retired) release_set(static_cast<PlaceSet *>(p));
+    ctx->place_retired.clear();
+    return PFMSCAN_OK;
 }
 
 const char *pfmscan_place_note(const pfmscan_ctx *ctx) { return ctx ? ctx->place_note.c_str() : ""; }

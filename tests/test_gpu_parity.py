@@ -609,15 +609,22 @@ def test_placed_arrays_hold_what_is_written_and_scan_like_any_other(ctx, oracle)
     big = 96 << 20                                  # every array spans several 64 MB chunks (PFMSCAN_PLACE_CHUNK_MB below)
     os.environ["PFMSCAN_PLACE_CHUNK_MB"] = "64"
     try:
+        first_ptrs = None
         for cycle, plain in enumerate((False, True, False, False)):
             roomy = torch.cuda.mem_get_info()[0] > (110 << 30)       # the second attempt holds 48 GB and wants 96 GB spare
             if cycle == 3:
                 os.environ["PFMSCAN_PLACE_FORCE_RETRY"] = "1"      # the path taken when no pair of candidates is independent
+                big += 64 << 20                                     # other sizes: a new set, not the retired one of cycle 2
             arrs = ctx.place_alloc([big + n * 28, big + n * 8, big + n * 4, big + n], plain=plain)
             os.environ.pop("PFMSCAN_PLACE_FORCE_RETRY", None)
             note = ctx.place_note()
             assert ("NOT tuned" in note) == plain, note
             assert ("second attempt" in note) == (cycle == 3 and roomy), note
+            # a freed set is retired, not unmapped: the same request gets the same arrays back (no new address range)
+            if cycle == 0:
+                first_ptrs = [a.ptr for a in arrs]
+            assert ("handed out again" in note) == (cycle == 2), note
+            assert ([a.ptr for a in arrs] == first_ptrs) == (cycle in (0, 2))
             raw = [torch.as_tensor(a, device=dev) for a in arrs]
             assert all(t.data_ptr() == a.ptr and t.numel() == a.nbytes for t, a in zip(raw, arrs))
             pattern = [torch.randint(0, 255, (a.nbytes,), dtype=torch.uint8, device=dev) for a in arrs]
@@ -640,6 +647,15 @@ def test_placed_arrays_hold_what_is_written_and_scan_like_any_other(ctx, oracle)
             ctx.place_free(arrs[0])
         with pytest.raises(Exception):
             ctx.place_free(arrs[0])                  # freed already
+        ctx.place_trim()                             # the retired sets give their memory back; a new request measures again
+        arrs = ctx.place_alloc([big + n * 28, big + n * 8, big + n * 4, big + n])
+        assert "handed out again" not in ctx.place_note()
+        ctx.place_free(arrs[0])
+        # the address-space budget: ranges are never given back, so a context that keeps asking for NEW sizes is told to stop
+        os.environ["PFMSCAN_PLACE_VA_BUDGET_GB"] = "1"
+        with pytest.raises(MemoryError):
+            ctx.place_alloc([big + (1 << 20), big, big, big], plain=True)
+        os.environ.pop("PFMSCAN_PLACE_VA_BUDGET_GB", None)
         with pytest.raises(Exception):
             ctx.place_alloc([0, 16])
     finally:
