@@ -381,8 +381,9 @@ def main():
 
     # ---- this rank's memory floor (tools/hbm_mixed on THIS rank's GPU): a slow rank and a badly placed one look different
     rank_floor = None
-    if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32" and not args.from_host:
-        rank_floor = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned", device=local_rank)
+    if not is_lib and args.mode == "scores" and (seq_only or args.profile_dtype == "float32") and not args.from_host:
+        rank_floor = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned", device=local_rank,
+                                      c2=seq_only)
 
     # ---- per-rank parity sample (multi-GPU runs): a few records of THIS rank's shard against the CPU oracle
     rank_parity = None
@@ -483,13 +484,17 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": ("k_letters_pre" if args.mode != "scores" else "k_letters") if seq_only else (
+                "kernel": ("k_letters_pre" if args.mode != "scores" else ("k_letters_fixed" if 2 <= args.width <= 16 and not os.environ.get("PFMSCAN_LETTERS_GENERIC") else "k_letters")) if seq_only else (
                     "k_profile_fixed" if (args.mode in ("scores", "hits") and 9 <= args.width <= 18 and not os.environ.get("PFMSCAN_PROFILE_GENERIC")) else "k_profile"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
                 "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": alg_bytes,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             },
         }
+        if seq_only and args.mode == "scores" and rank_floor is not None:
+            # C2's byte mix (1 B read + 4 B written per position) moved by a program that scores nothing: tools/hbm_mixed ... c2
+            result["roofline"]["mixed_read_write_floor"] = dict(rank_floor, frac_of_floor=rank_floor["ms"] / kernel_ms,
+                                                                kernel_over_floor=kernel_ms / rank_floor["ms"])
         if not seq_only and not is_lib and args.mode == "scores" and args.profile_dtype == "float32":
             # the same byte mix (29 B in + 12 B out per position) moved by a program that scores nothing
             # (tools/hbm_mixed.hip, measured on this chip in round 4): what the memory system gives this access pattern

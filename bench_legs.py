@@ -128,7 +128,7 @@ def pmc_entry(workload):
     return {}
 
 
-def live_mixed_floor(records, length, placed=False, device=0):
+def live_mixed_floor(records, length, placed=False, device=0, c2=False):
     """tools/hbm_mixed `quick` as a child process on the same GPU, right after the timed region: the fastest of its
     read+write forms is what THIS box's memory system gives the headline's byte mix (29 B in + 12 B out per position,
     nothing scored).  None when the tool is not built (rnascan_amd/build.py: build_floor_tool)."""
@@ -141,7 +141,7 @@ def live_mixed_floor(records, length, placed=False, device=0):
         env = dict(os.environ)
         vis = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
         env["HIP_VISIBLE_DEVICES"] = vis[device] if device < len(vis) else str(device)          # the child sees only this rank's GPU
-        out = subprocess.run([exe, str(records), str(length), "quick"] + (["placed"] if placed else []), capture_output=True, text=True,
+        out = subprocess.run([exe, str(records), str(length), "quick"] + (["placed"] if placed else []) + (["c2"] if c2 else []), capture_output=True, text=True,
                              timeout=120, env=env)
     except (OSError, subprocess.TimeoutExpired):
         return None
@@ -149,7 +149,8 @@ def live_mixed_floor(records, length, placed=False, device=0):
         if ln.startswith("floor_ms "):
             f = ln.split()
             return {"ms": float(f[1]), "tb_per_s": float(f[3]), "bytes": float(f[5]),
-                    "source": "tools/hbm_mixed %d %d quick%s, run by this bench.py on the same GPU after the timed region" % (records, length, " placed" if placed else ""),
+                    "source": "tools/hbm_mixed %d %d quick%s%s, run by this bench.py on the same GPU after the timed region" % (
+                        records, length, " placed" if placed else "", " c2" if c2 else ""),
                     "arrays": "pfmscan_place_alloc, like the bench's own" if placed else "hipMalloc, wherever the driver puts them",
                     "note": "fastest of 4 read+write forms (vector-load tiles, LDS-DMA tiles) in 3 rounds, each the median of 5 x 20 passes; "
                             "the figure moves by up to 10 % from one minute to the next on one box, like the kernel's own time"}

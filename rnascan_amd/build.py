@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpfmscan.so")
-SOURCES = ["pfmscan_kernels.hip", "pfmscan_letters8.hip", "pfmscan_api.hip", "pfmscan_sort.hip", "pfmscan_library.hip", "pfmscan_library_api.hip", "pfmscan_proflib.hip", "pfmscan_profile_fixed.hip", "pfmscan_place.hip",
+SOURCES = ["pfmscan_kernels.hip", "pfmscan_letters8.hip", "pfmscan_letters_fixed.hip", "pfmscan_api.hip", "pfmscan_sort.hip", "pfmscan_library.hip", "pfmscan_library_api.hip", "pfmscan_proflib.hip", "pfmscan_profile_fixed.hip", "pfmscan_place.hip",
            "pfmscan_pipeline.hip", "pfmscan_ingest.hip", "pfmscan_upload.hip"]
 HEADERS = ["pfmscan_internal.hpp", "pfmscan_ctx.hpp", "pfmscan_device.hpp", "pfmscan_profile.hpp", "pfmscan_exact.hpp", os.path.join("..", "..", "include", "pfmscan.h")]
 DEPS = SOURCES + HEADERS

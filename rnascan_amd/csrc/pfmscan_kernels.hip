@@ -123,21 +123,22 @@ __global__ __launch_bounds__(BLOCK) void k_letters(const ScanArgs a)
 #pragma unroll
             for (int j = 0; j < (NDW - 1) * 4; ++j) {
                 if (j < m) {
-                    const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+                    // (volatile: one ds_read_b64 per look-up; paired into ds_read2_b64 they run at half the LDS rate, see k_letters_fixed)
+                    const __attribute__((address_space(3))) char *row = (const __attribute__((address_space(3))) char *)reinterpret_cast<const char *>(tbl) + j * 64;
 #pragma unroll
-                    for (int v = 0; v < W; ++v) acc[v] += *reinterpret_cast<const double *>(row + adr[j + v]);
+                    for (int v = 0; v < W; ++v) acc[v] += *(const volatile __attribute__((address_space(3))) double *)(row + adr[j + v]);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < (NDW - 1) * 4; ++j) {
                 if (j < m) {
-                    const char *row = reinterpret_cast<const char *>(tbl) + j * 64;
+                    const __attribute__((address_space(3))) char *row = (const __attribute__((address_space(3))) char *)reinterpret_cast<const char *>(tbl) + j * 64;
 #pragma unroll
                     for (int v = 0; v < W; ++v) {
                         const int q = j + v;    // byte index relative to p0, compile-time
                         const uint32_t b = (w[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
-                        acc[v] += *reinterpret_cast<const double *>(row + b);
+                        acc[v] += *(const volatile __attribute__((address_space(3))) double *)(row + b);
                     }
                 }
             }
@@ -1358,6 +1359,7 @@ static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t
     if (launch_letters_quad(a, t, stream, &e)) return e;     // PFMSCAN_QUAD=1 only: measured slower (profiles/r3/NOTES.md, "tried and dropped")
     if (launch_letters_cred(a, t, stream, &e)) return e;
     if (launch_letters_cred8(a, t, stream, &e)) return e;    // fp64 hits of a generic alphabet at a finite threshold
+    if (launch_letters_fixed(a, stream, &e)) return e;       // all float32 scores, widths 2 .. 16: the width is a compile-time constant
     if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
     if (a.m <= 32) return launch_letters_ndw<9>(a, t, stream);
     return launch_letters_ndw<17>(a, t, stream);

@@ -10,7 +10,7 @@
 //   lds      the same with the tile staged through LDS by LDS-DMA (global_load_lds_dwordx4), as k_profile stages it
 //   read     inputs only            write    outputs only
 // swept over tile sizes and resident workgroups per CU.
-//   hipcc -O3 --offload-arch=gfx950 tools/hbm_mixed.hip -o tools/hbm_mixed && tools/hbm_mixed [records] [length] [quick] [placed]   (-ldl)
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_mixed.hip -o tools/hbm_mixed && tools/hbm_mixed [records] [length] [quick] [placed] [c2]   (-ldl)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -35,6 +35,7 @@ struct Args {
     int64_t n_pos;
     int do_read, do_write;
     int fronts;                      // k_lds: workgroup b takes tile b / F of part b % F (the stream walked at F places at once)
+    int c2;                          // C2's byte mix instead (`c2` on the command line): 1 code byte read, ONE float32 written per position
 };
 
 // one workgroup = one tile of TILE positions; every thread moves 16 bytes per access
@@ -46,10 +47,12 @@ __global__ __launch_bounds__(BLOCK) void k_copy(const Args a)
     if (a.do_read) {
         const u32x4 *p = reinterpret_cast<const u32x4 *>(a.profile + tile0 * 28);
         constexpr int NV = TILE * 28 / 16;
+        if (!a.c2) {
 #pragma unroll 4
-        for (int c = threadIdx.x; c < NV; c += BLOCK) {
-            const u32x4 v = NT_LOAD ? __builtin_nontemporal_load(p + c) : p[c];
-            acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+            for (int c = threadIdx.x; c < NV; c += BLOCK) {
+                const u32x4 v = NT_LOAD ? __builtin_nontemporal_load(p + c) : p[c];
+                acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+            }
         }
         const u32x4 *q = reinterpret_cast<const u32x4 *>(a.codes + tile0);
         for (int c = threadIdx.x; c < TILE / 16; c += BLOCK) {
@@ -63,10 +66,12 @@ __global__ __launch_bounds__(BLOCK) void k_copy(const Args a)
         f64x2 *o2 = reinterpret_cast<f64x2 *>(a.out_struct + tile0);
         if (ST == 1) {
             for (int c = threadIdx.x; c < TILE / 4; c += BLOCK) o[c] = f32x4{f, f, f, f};
-            for (int c = threadIdx.x; c < TILE / 2; c += BLOCK) o2[c] = f64x2{(double)f, (double)f};
+            if (!a.c2)
+                for (int c = threadIdx.x; c < TILE / 2; c += BLOCK) o2[c] = f64x2{(double)f, (double)f};
         } else {
             for (int c = threadIdx.x; c < TILE / 4; c += BLOCK) __builtin_nontemporal_store(f32x4{f, f, f, f}, o + c);
-            for (int c = threadIdx.x; c < TILE / 2; c += BLOCK) __builtin_nontemporal_store(f64x2{(double)f, (double)f}, o2 + c);
+            if (!a.c2)
+                for (int c = threadIdx.x; c < TILE / 2; c += BLOCK) __builtin_nontemporal_store(f64x2{(double)f, (double)f}, o2 + c);
         }
     } else if (acc == 0x12345678u) {
         a.out_seq[0] = 1.0f;
@@ -185,7 +190,7 @@ int main(int argc, char **argv)
     const int64_t records = argc > 1 ? std::atoll(argv[1]) : 100000, length = argc > 2 ? std::atoll(argv[2]) : 3000;
     for (int i = 3; i < argc; ++i) g_quick = g_quick || std::strcmp(argv[i], "quick") == 0;
     int64_t n_pos = records * (length + 1);
-    n_pos -= n_pos % 8192;                                      // whole tiles for every tile size below
+    n_pos -= n_pos % 16384;                                     // whole tiles for every tile size below
     Args a;
     bool placed = false;
     for (int i = 3; i < argc; ++i) placed = placed || std::strcmp(argv[i], "placed") == 0;
@@ -222,6 +227,28 @@ int main(int argc, char **argv)
     a.n_pos = n_pos;
     a.do_read = a.do_write = 1;
     a.fronts = 1;
+    a.c2 = 0;
+    for (int i = 3; i < argc; ++i) a.c2 = a.c2 || std::strcmp(argv[i], "c2") == 0;
+    if (a.c2) {
+        // BASELINE config 2's byte mix (sequence-only all-scores scan): 1 code byte in, one float32 out per position --
+        // 0.30 GB read + 1.20 GB written on 100k x 3 kb: a write stream with a trickle of reads beside it
+        const double cr = (double)n_pos, cw = (double)n_pos * 4;
+        std::printf("positions %lld: %.3f GB read + %.3f GB written = %.3f GB per pass (C2's byte mix)\n", (long long)n_pos, cr * 1e-9, cw * 1e-9,
+                    (cr + cw) * 1e-9);
+        for (int round = 0; round < (g_quick ? 3 : 1); ++round) {
+            run_copy<4096, 256, true>("c2 copy  tile 4096, nt loads", a, cr, cw);
+            run_copy<8192, 256, true>("c2 copy  tile 8192, nt loads", a, cr, cw);
+            run_copy<16384, 256, true>("c2 copy  tile 16384, nt loads", a, cr, cw);
+            run_copy<4096, 256, false>("c2 copy  tile 4096, plain loads", a, cr, cw);
+            if (!g_quick) {
+                run_copy<4096, 256, true, 1>("c2 copy  tile 4096, plain stores", a, cr, cw);
+                run_copy<8192, 512, true>("c2 copy  tile 8192, 512 threads", a, cr, cw);
+                run_copy<8192, 256, true>("c2 copy  tile 8192, grid 256 x 16", a, cr, cw, 4096);
+            }
+        }
+        std::printf("floor_ms %.4f tb_per_s %.3f bytes %.0f\n", g_best_rw, (cr + cw) / g_best_rw * 1e-9, cr + cw);
+        return 0;
+    }
     const double br = (double)n_pos * 29, bw = (double)n_pos * 12;
     std::printf("positions %lld: %.3f GB read + %.3f GB written = %.3f GB per pass (C3's launch moves 12.287 GB)\n", (long long)n_pos,
                 br * 1e-9, bw * 1e-9, (br + bw) * 1e-9);
