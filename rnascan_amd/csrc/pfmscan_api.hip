@@ -123,8 +123,7 @@ void pfmscan_ctx_destroy(pfmscan_ctx *ctx)
                       &ctx->cand_count, &ctx->sort_keys_in, &ctx->sort_keys_out, &ctx->sort_vals_in, &ctx->sort_vals_out,
                       &ctx->sort_temp, &ctx->sort_seq, &ctx->sort_struct, &ctx->hit_motif, &ctx->sort_motif, &ctx->lib_pos,
                       &ctx->lib_motif, &ctx->lib_seq, &ctx->lib_struct, &ctx->lib_count, &ctx->pipe_codes[0], &ctx->pipe_codes[1],
-                      &ctx->pipe_profile[0], &ctx->pipe_profile[1], &ctx->codes2, &ctx->lib_list[0], &ctx->lib_list[1],
-                      &ctx->lib_list[2], &ctx->lib_list_count})
+                      &ctx->pipe_profile[0], &ctx->pipe_profile[1], &ctx->codes2})
         release(*b);
     upload_release(ctx);
     place_release_all(ctx);

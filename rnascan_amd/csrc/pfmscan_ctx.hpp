@@ -50,7 +50,6 @@ struct pfmscan_ctx {
     DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, sort_seq, sort_struct;   // pfmscan_sort.hip
     DevBuf hit_motif, sort_motif;               // library scans: motif index per hit
     DevBuf lib_pos, lib_motif, lib_seq, lib_struct, lib_count;   // library scans: sharded hits of the _dev form
-    DevBuf lib_list[3], lib_list_count;         // library scans, split form: per-workgroup item lists between the prefilter and the verify launch
     DevBuf pipe_codes[2], pipe_profile[2];      // chunked host pipeline: double-buffered chunk of the stream
     hipEvent_t pipe_copied[2] = {nullptr, nullptr}, pipe_scanned[2] = {nullptr, nullptr};
     // host ranges known to be read-only mappings of files (pfmscan_upload_source_file): the staged uploader preads them

@@ -200,12 +200,6 @@ struct LibArgs {
     int team_first[5];
     int team_ng[4];                       // ng_real per team
     int64_t stride_pairs, stride_letters, stride_pssm, stride_thr;      // in elements of the respective arrays
-    // Split form (launch_library_split): the prefilter launch appends its flagged windows to ONE list per workgroup -- items
-    // (relative position, group mask, letters) in three arrays, workgroup b's region = [b * list_cap, (b + 1) * list_cap), its
-    // length in list_count[b] -- and the verify launch (same grid, same teams) gives them their exact scores
-    uint32_t *list_pos, *list_gm, *list_cw;
-    uint32_t *list_count;
-    int64_t list_cap;
     // hits: LIB_SHARDS (or 1) regions of shard_cap slots, counters HIT_COUNTER_STRIDE words apart
     int64_t shard_cap;
     int hit_shards;
@@ -221,11 +215,6 @@ size_t lib_lds_bytes(int m, int npair, int ng, bool has_struct, int np_bucket);
 int lib_np_bucket(int m);
 int lib_pick_ng(int np_bucket, int want_groups, int max_groups);   // supported group count of a pass (0: none fits)
 hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream);
-// the same pass(es) as two launches: a prefilter kernel (phase A alone: the LDS look-up pipe never waits for a gather) that
-// writes its flagged windows to per-workgroup lists in global memory, and a verify kernel (phase B alone: every wave of the chip
-// hides gather latency).  PFMs up to 16 wide with a structure side; false: not this form's case (the caller launches the fused kernel)
-bool launch_library_split(const LibArgs &a, int n_cu, hipStream_t stream, hipError_t *err);
-int64_t library_split_list_cap(const LibArgs &a, int n_cu);       // items a workgroup's list must hold (every window of its segments)
 // LibArgs::profile_dtype of a two-FASTA library: `profile` is the SECOND code stream and `pssm` holds [m][8] letter tables
 constexpr int PROFILE_LETTERS2 = 100;
 // generic-alphabet letter libraries (k_library8): `pairs` = single-letter credits [rows][ng][8 codes][8 motifs] u16, `npair` =

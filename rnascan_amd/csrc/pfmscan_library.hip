@@ -349,19 +349,9 @@ __device__ __forceinline__ int lib_dispatch(const int npair, const int g, const 
 }
 
 // NG = motif groups of the pass, NP = pair rows the code is unrolled for (8 / 16 / 32 for m <= 16 / 32 / 64)
-// MODE 0: both phases in one kernel.  MODE 1 / 2 (twelve-motif entries with a structure side only): the SPLIT form.
-//   1 = phase A and the exact SEQUENCE pass of phase B (LDS only: the items carry their letters); what passes the sequence
-//       threshold -- (relative position, pass-local motif, float32 score) -- is appended to the workgroup's list in global memory
-//       (one LDS atomic per batch reserves the slots, the lanes write side by side);
-//   2 = the exact STRUCTURE pass alone, fed from that list 64 items at a time: every lane of a batch has a window to gather
-//       (in the fused kernel a batch gathers for the ~half of its lanes that passed the sequence threshold, and every batch is
-//       a dependent chain of LDS look-ups and two gather round trips that the wave sits out).
-// A first split at the prefilter boundary (the whole phase B as the second launch) LOST: phase B alone is latency-bound, 7.5 ms
-// against the 4.3 it adds to phase A's 5.2 when interleaved (profiles/r5/ab_c5_split_phaseA_phaseB.txt).
-template <int NG, int NP, typename PROF_T, bool HAS_STRUCT, int MODE = 0>
+template <int NG, int NP, typename PROF_T, bool HAS_STRUCT>
 __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
 {
-    static_assert(MODE == 0 || lib_mpg(NP) == 12, "the split form is built for the twelve-motifs-per-entry items");
     constexpr int LIB_BLOCK = lib_block(NP);
     constexpr int LIB_WAVES = LIB_BLOCK / 64;
     constexpr int MPG = lib_mpg(NP);                // motifs per table entry: 12 (10-bit credits) or 8 (16-bit)
@@ -411,14 +401,7 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         thr_s[i] = g_thr_seq[i];
         thr_t[i] = HAS_STRUCT ? g_thr_struct[i] : -INFINITY;
     }
-    // split form: slots reserved in the workgroup's list, waves that are done, first reservation that did not fit
-    uint32_t *cursor = ticket + 1, *finished = ticket + 2, *limit = ticket + 3;
-    if (threadIdx.x == 0) {
-        *ticket = LIB_WAVES;                        // the first chunk of wave w is chunk w
-        *cursor = 0u;
-        *finished = 0u;
-        *limit = 0xFFFFFFFFu;
-    }
+    if (threadIdx.x == 0) *ticket = LIB_WAVES;      // the first chunk of wave w is chunk w
     __syncthreads();                                // the only workgroup barrier: waves are independent from here on
 
     const int64_t n_pos = a.n_pos;
@@ -547,35 +530,6 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         const float f = (float)sc;
         bool ok = act && ((double)f > thr_s[mo]);
         double st = 0.0;
-        if constexpr (MODE == 1) {
-            // split form: what passed the sequence threshold goes to the workgroup's list; the structure pass is another launch
-            const unsigned long long om = __builtin_amdgcn_ballot_w64(ok);
-            bool listed = true;
-            if (om) {                                            // wave-uniform
-                const uint32_t n_ok = (uint32_t)__popcll(om);
-                uint32_t lb = 0;
-                if (lane == 0) {
-                    lb = atomicAdd(cursor, n_ok);
-                    // a reservation that does not fit ends the list where it starts (the cursor only grows: none after it fits
-                    // either); such a batch -- a list sized for one sequence hit per window is full -- takes the fused path below
-                    if ((int64_t)lb + (int64_t)n_ok > a.list_cap) atomicMin(limit, lb);
-                }
-                lb = __builtin_amdgcn_readfirstlane(lb);
-                listed = (int64_t)lb + (int64_t)n_ok <= a.list_cap;
-                if (listed && ok) {
-                    const uint32_t i = lb + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
-                    const size_t at = (size_t)blockIdx.x * (size_t)a.list_cap + i;
-                    a.list_pos[at] = rel;
-                    a.list_gm[at] = (uint32_t)mo;
-                    a.list_cw[at] = __float_as_uint(f);
-                }
-            }
-            if (listed) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                return;
-            }
-        }
         if (HAS_STRUCT) {
             if (__builtin_amdgcn_ballot_w64(ok)) {
                 if (ok) {
@@ -639,54 +593,6 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         if (!AHEAD && lane == 0) drawn = atomicAdd(ticket, 1u);
         return __builtin_amdgcn_readfirstlane(drawn);
     };
-    if constexpr (MODE == 2) {
-        // ---- structure pass: this workgroup's list of sequence hits (written by the MODE 1 launch of the same grid) ----
-        const uint32_t cnt = a.list_count[blockIdx.x];
-        const size_t lbase = (size_t)blockIdx.x * (size_t)a.list_cap;
-        const uint32_t n_blocks = (cnt + 63u) >> 6;
-        for (uint32_t u = (uint32_t)wave; u < n_blocks; u = next_unit()) {
-            if (AHEAD && lane == 0) drawn = atomicAdd(ticket, 1u);
-            const uint32_t i = (u << 6) + (uint32_t)lane;
-            const bool have = i < cnt;
-            const uint32_t rel = have ? a.list_pos[lbase + i] : 0u;
-            const int mo = have ? (int)a.list_gm[lbase + i] : 0;
-            const float f = __uint_as_float(have ? a.list_cw[lbase + i] : 0u);
-            const int64_t p = a.pos_base + (int64_t)rel;
-            double st = 0.0;
-            bool ok = false;
-            if (have) {
-                if constexpr (!std::is_same<PROF_T, uint8_t>::value) {
-                    bool exact = !a.struct_finite;                       // wave-uniform
-                    if (a.struct_finite) {
-                        st = lib_struct_score<PROF_T, NMP, true>(a.profile, p, m, pssm, mo);
-                        exact = !(fabs(st) <= DBL_MAX);
-                    }
-                    if (exact) st = lib_struct_score<PROF_T, NMP, false>(a.profile, p, m, pssm, mo);
-                    if (struct_near(st, thr_t[mo], a.struct_band))
-                        st = struct_window_rounded(reinterpret_cast<const PROF_T *>(a.profile) + p * 7, m,
-                                                   [&](int j, int k) { return pssm[((size_t)(j * 4 + (k >> 1)) * NMP + mo) * 2 + (k & 1)]; });
-                }
-                ok = st > thr_t[mo];
-            }
-            const unsigned long long hm = __builtin_amdgcn_ballot_w64(ok);
-            if (hm) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(hm));
-                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-                base = ((unsigned long long)hi << 32) | lo;
-                if (ok) {
-                    const unsigned long long slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                    if ((int64_t)slot < a.shard_cap) {
-                        a.hit_pos[shard_off + slot] = p + a.pos_offset;
-                        a.hit_motif[shard_off + slot] = motif_base + mo;
-                        a.hit_seq[shard_off + slot] = f;
-                        a.hit_struct[shard_off + slot] = st;
-                    }
-                }
-            }
-        }
-        return;
-    } else
     for (uint32_t u = (uint32_t)wave; u < n_units; u = next_unit()) {
         if (AHEAD && lane == 0) drawn = atomicAdd(ticket, 1u);
         {
@@ -773,16 +679,6 @@ __global__ __launch_bounds__(lib_block(NP)) void k_library(const LibArgs a)
         dense(0, qn);
         qn = requeued;
     }
-    if constexpr (MODE == 1) {
-        // the last wave of the workgroup to get here publishes the list's length (every wave's reservations precede its count)
-        if (lane == 0) {
-            const uint32_t done = atomicAdd(finished, 1u);
-            if (done == (uint32_t)LIB_WAVES - 1u) {
-                const uint32_t n = atomicAdd(cursor, 0u), lim = atomicMin(limit, 0xFFFFFFFFu);
-                a.list_count[blockIdx.x] = n < lim ? n : lim;
-            }
-        }
-    }
 }
 
 // LDS bytes of one motif group of a pass (must match the carve-up in k_library): its slice of every pair row and of the
@@ -838,47 +734,6 @@ static hipError_t launch_library_ng(const LibArgs &a, unsigned grid, size_t lds,
     if (a.profile_dtype == PROFILE_LETTERS2) return launch_library_inst<NG, NP, uint8_t, true>(a, grid, lds, stream);     // two-FASTA library
     if (a.profile_dtype == PFMSCAN_PROFILE_F64) return launch_library_inst<NG, NP, double, true>(a, grid, lds, stream);
     return launch_library_inst<NG, NP, float, true>(a, grid, lds, stream);
-}
-
-template <int NG, typename PROF_T>
-static hipError_t launch_library_split_inst(const LibArgs &a, unsigned grid, size_t lds, hipStream_t stream)
-{
-    auto pre = k_library<NG, 8, PROF_T, true, 1>;
-    auto ver = k_library<NG, 8, PROF_T, true, 2>;
-    static std::atomic<uint64_t> c1{0}, c2{0};
-    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(pre), c1, 160 * 1024);
-    if (e == hipSuccess) e = allow_dynamic_lds(reinterpret_cast<const void *>(ver), c2, 160 * 1024);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pre, dim3(grid), dim3(lib_block(8)), lds, stream, a);
-    hipLaunchKernelGGL(ver, dim3(grid), dim3(lib_block(8)), lds, stream, a);
-    return hipGetLastError();
-}
-
-// items the list of one workgroup must hold: every window of the segments it visits (worst case), over all teams
-int64_t library_split_list_cap(const LibArgs &a, int n_cu)
-{
-    const int64_t grid = std::min<int64_t>(a.n_seg, n_cu);
-    int64_t smallest = grid;
-    if (a.n_teams > 1)
-        for (int t = 0; t < a.n_teams; ++t) smallest = std::min<int64_t>(smallest, a.team_first[t + 1] - a.team_first[t]);
-    smallest = std::max<int64_t>(smallest, 1);
-    return (a.n_seg + smallest - 1) / smallest * a.seg_positions;
-}
-
-bool launch_library_split(const LibArgs &a, int n_cu, hipStream_t stream, hipError_t *err)
-{
-    if (a.span <= 0 || a.nmp <= 0 || !a.pssm || !a.list_pos || !a.list_gm || !a.list_cw || !a.list_count) return false;
-    if (lib_np_bucket(a.m) != 8 || a.profile_dtype == PROFILE_LETTERS2 || (a.ng != 8 && a.ng != 11 && a.ng != 16)) return false;
-    const size_t lds = lib_lds_bytes(a.m, a.npair, a.ng, true, 8);
-    if (lds > 160 * 1024 || a.ng * 12 != a.nmp || a.seg_positions != ((int64_t)1 << LIB_SEG_SHIFT) || a.list_cap < library_split_list_cap(a, n_cu) ||
-        a.list_cap > 0xFFFFFFFFll || ((a.n_seg + n_cu - 1) / n_cu) * (a.seg_positions >> 6) > 0x7FFFFFFF)
-        return false;
-    const unsigned grid = (unsigned)std::min<int64_t>(a.n_seg, n_cu);
-    const bool f64 = a.profile_dtype == PFMSCAN_PROFILE_F64;
-    if (a.ng == 8) *err = f64 ? launch_library_split_inst<8, double>(a, grid, lds, stream) : launch_library_split_inst<8, float>(a, grid, lds, stream);
-    else if (a.ng == 11) *err = f64 ? launch_library_split_inst<11, double>(a, grid, lds, stream) : launch_library_split_inst<11, float>(a, grid, lds, stream);
-    else *err = f64 ? launch_library_split_inst<16, double>(a, grid, lds, stream) : launch_library_split_inst<16, float>(a, grid, lds, stream);
-    return true;
 }
 
 hipError_t launch_library(const LibArgs &a, int n_cu, hipStream_t stream)

@@ -681,32 +681,6 @@ static int lib_run(pfmscan_ctx *ctx, pfmscan_library *lib, const uint8_t *d_code
             a.hit_seq = sink.seq;
             a.hit_struct = sink.st;
             a.hit_count = sink.count;
-            // Long streams with a structure side, PFMs up to 16 wide: the SPLIT form -- a prefilter launch (phase A alone) that
-            // leaves its flagged windows in per-workgroup lists, then a verify launch (phase B alone) over the same grid.
-            // The lists are sized for the worst case (every window flagged); PFMSCAN_LIB_SPLIT=0: the fused kernel (A/B, tests)
-            static const int split_env = std::getenv("PFMSCAN_LIB_SPLIT") ? std::atoi(std::getenv("PFMSCAN_LIB_SPLIT")) : -1;
-            const int64_t split_min = split_env == 1 ? 0 : (int64_t)8 * ctx->n_cu * LIB_SEG;
-            if (split_env != 0 && lib->has_struct && !lib->pair && lib->np_bucket == 8 && a.span >= split_min) {
-                const int64_t cap = library_split_list_cap(a, ctx->n_cu);
-                const int64_t grid = std::min<int64_t>(a.n_seg, ctx->n_cu);
-                const size_t bytes = (size_t)cap * (size_t)grid * 4;
-                if (cap <= 0xFFFFFFFFll && bytes * 3 <= ((size_t)32 << 30)) {
-                    int rc;
-                    if ((rc = ensure(ctx, ctx->lib_list[0], bytes)) || (rc = ensure(ctx, ctx->lib_list[1], bytes)) ||
-                        (rc = ensure(ctx, ctx->lib_list[2], bytes)) || (rc = ensure(ctx, ctx->lib_list_count, (size_t)grid * 4)))
-                        return rc;
-                    a.list_pos = (uint32_t *)ctx->lib_list[0].p;
-                    a.list_gm = (uint32_t *)ctx->lib_list[1].p;
-                    a.list_cw = (uint32_t *)ctx->lib_list[2].p;
-                    a.list_count = (uint32_t *)ctx->lib_list_count.p;
-                    a.list_cap = cap;
-                    hipError_t es = hipSuccess;
-                    if (launch_library_split(a, ctx->n_cu, st, &es)) {
-                        if (es != hipSuccess) return fail_hip(ctx, es, "launch k_library (split form)");
-                        continue;
-                    }
-                }
-            }
             hipError_t e = launch_library(a, ctx->n_cu, st);
             if (e != hipSuccess) return fail_hip(ctx, e, "launch k_library");
         }
