@@ -134,6 +134,13 @@ if NLIB:
     runs.append(("library: %d pairs, seq + struct (store) -m 6" % NLIB,
                  ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", "--profile-dtype", "float32", fa, sd]))
     runs.append(("library: %d seq PFMs -m 6" % NLIB, ["-p", lib_s, "-C", "0.01", "-u", "-m", "6", fa]))
+    # the letter libraries (SURVEY 8f N1 x N4): structure-letter PFMs over a structure FASTA, and pairs over two FASTA files
+    runs.append(("library: %d structure-letter PFMs, -q lib structs.fa -m 6" % NLIB, ["-q", lib_t, "-C", "0.01", "-u", "-m", "6", sfa]))
+    runs.append(("library: %d pairs, two FASTA -p lib -q lib seqs.fa structs.fa -m 6" % NLIB,
+                 ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", fa, sfa]))
+    if RBIG:
+        runs.append(("big library: %d structure-letter PFMs, -q lib structs.fa -m 6" % NLIB, ["-q", lib_t, "-C", "0.01", "-u", "-m", "6", bigs]))
+        runs.append(("big library: %d pairs, two FASTA -m 6" % NLIB, ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", big, bigs]))
     if RBIG and BIGSTORE:
         runs.append(("big library: %d pairs, seq + struct (store) -m 6" % NLIB,
                      ["-p", lib_s, "-q", lib_t, "-C", "0.01", "-u", "-m", "6", "--profile-dtype", "float32", big, bigsd]))
