@@ -354,7 +354,10 @@ def main():
     # the timed region and under the same clocks: the line carries both, so the kernel's share and the placement's share of
     # the headline can be told apart in one record
     default_alloc = None
-    if placed is not None and args.mode == "scores" and not is_lib and not os.environ.get("PFMSCAN_BENCH_NO_DEFAULT_ALLOC"):
+    # (not under a profiler: the kernel trace's average for this kernel is compared with `kernel_ms`, which times the placed arrays)
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
+        bool(os.environ.get("PFMSCAN_BENCH_NO_FLOOR"))
+    if placed is not None and args.mode == "scores" and not is_lib and not os.environ.get("PFMSCAN_BENCH_NO_DEFAULT_ALLOC") and not under_profiler:
         try:
             d_codes, d_prof = codes.clone(), (None if seq_only else profile.clone())
             d_seq, d_st = torch.zeros(n_pos, dtype=torch.float32, device=dev), (None if seq_only else torch.zeros(n_pos, dtype=torch.float64, device=dev))

@@ -43,8 +43,11 @@ struct Cred8Table {
 
 constexpr int Q8_CAP = 128;                            // hits a wave can park (12 bytes each)
 
+#ifndef CRED8_MIN_WG
+#define CRED8_MIN_WG                                   // A/B builds: -DCRED8_MIN_WG=",4" (tools/build_variant.sh)
+#endif
 template <int NJ>
-__global__ __launch_bounds__(BLOCK) void k_letters_cred8(const ScanArgs a, const Cred8Table ct)
+__global__ __launch_bounds__(BLOCK CRED8_MIN_WG) void k_letters_cred8(const ScanArgs a, const Cred8Table ct)
 {
     constexpr int W = 16;                              // windows per lane = one round per tile
     constexpr int LET_TILE = BLOCK * W;
