@@ -661,3 +661,30 @@ def test_placed_arrays_hold_what_is_written_and_scan_like_any_other(ctx, oracle)
     finally:
         del os.environ["PFMSCAN_PLACE_CHUNK_MB"]
     motif.close()
+
+
+@pytest.mark.parametrize("m", list(range(2, 17)))
+def test_fixed_width_letters_kernel_equals_the_generic_one(ctx, oracle, monkeypatch, m):
+    """k_letters_fixed (all float32 scores, widths 2..16: four windows per lane, rows 0 + 1 as one pair look-up built in the
+    reference's order) gives the width-generic k_letters' bits -- and the oracle's -- on ragged records with foreign letters,
+    -inf cells, 8-letter codes and every tail length of the last tile"""
+    rng = np.random.default_rng(4000 + m)
+    T = rand_table(rng, m, nletters=4 if m % 2 else 7, inf_frac=0.1 if m % 3 == 0 else 0.0)
+    motif = ctx.motif(letter_table=T)
+    for extra in (0, 1, 2, 3, 5, 4095, 4096, 4097):
+        lengths = [3000, 0, m - 1, m, m + 1, 777] + ([extra] if extra else [])
+        codes = []
+        for L in lengths:
+            c = rng.integers(0, 7 if m % 2 == 0 else 4, size=L).astype(np.uint8)
+            c[rng.random(L) < 0.01] = 7
+            codes.append(c)
+        s = pack.pack(codes)
+        want = oracle.stream_seq(s.codes, T)
+        got, _ = ctx.scan_host(motif, s.codes)
+        monkeypatch.setenv("PFMSCAN_LETTERS_GENERIC", "1")
+        gen, _ = ctx.scan_host(motif, s.codes)
+        monkeypatch.delenv("PFMSCAN_LETTERS_GENERIC")
+        keep = s.window_mask(m)
+        assert_f32_bits_equal(got[keep], want[keep])
+        assert np.array_equal(got.view(np.uint32)[~np.isnan(got)], gen.view(np.uint32)[~np.isnan(gen)]) and np.array_equal(np.isnan(got), np.isnan(gen))
+    motif.close()
