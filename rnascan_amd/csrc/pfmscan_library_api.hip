@@ -412,8 +412,9 @@ int pfmscan_library_info(const pfmscan_library *lib, int *n_motifs, int *m, int 
     if (!lib) return PFMSCAN_E_BADARG;
     if (n_motifs) *n_motifs = lib->n;
     if (m) *m = lib->m;
-    if (n_passes) *n_passes = lib->has_letters ? (int)lib->passes.size() : 1;
-    if (motifs_per_pass) *motifs_per_pass = !lib->has_letters ? lib->n : (lib->passes.empty() ? 0 : lib->passes[0].nmp);
+    const bool tabled = lib->has_letters || lib->letters8;          // passes of LDS tables (a structure-only profile library is one pass whatever its size)
+    if (n_passes) *n_passes = tabled ? (int)lib->passes.size() : 1;
+    if (motifs_per_pass) *motifs_per_pass = !tabled ? lib->n : (lib->passes.empty() ? 0 : lib->passes[0].nmp);
     if (max_eps) {
         double mx = 0.0;
         for (double v : lib->eps) mx = std::max(mx, v);

@@ -289,3 +289,13 @@ def test_cli_two_fasta_libraries_equal_the_per_pair_run(engine, tmp_path, monkey
         if extra == ["-m", "-1"]:
             assert got.count("\n") > 20
     assert len(calls) >= 3 * 5
+
+
+def test_letter_library_info_reports_its_passes(ctx):
+    """128 structure-letter PFMs of width 12 fit the LDS at once (16 groups of 8), 300 need three passes"""
+    rng = np.random.default_rng(2)
+    for n, passes in ((128, 1), (129, 2), (300, 3)):
+        lib = ctx.library(None, struct_letters=np.stack([_table(rng, 12) for _ in range(n)]))
+        info = lib.info()
+        assert info["n_motifs"] == n and info["m"] == 12 and info["passes"] == passes and info["motifs_per_pass"] == 128
+        lib.close()

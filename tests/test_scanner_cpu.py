@@ -463,3 +463,66 @@ def test_float32_store_under_float64_rows_is_scanned_in_place(tmp_path):
             tables[(sdtype, rows)] = df
     pd.testing.assert_frame_equal(tables[(np.float32, np.float32)], tables[(np.float32, np.float64)])
     pd.testing.assert_frame_equal(tables[(np.float32, np.float32)], tables[(np.float64, np.float32)])
+
+
+class _OracleLetterLibraries(OracleEngine):
+    """OracleEngine + the letter-library entry point of HipEngine (per-motif oracle scans merged into the (position, motif) order the
+    device returns): lets the scanner's letter-library branches run on a machine without a GPU"""
+
+    def library_hits_letters(self, stream, seq_tables, struct_tables, thr_seq, thr_struct):
+        from oracle import oracle
+        n = struct_tables.shape[0]
+        tt = np.broadcast_to(np.asarray(thr_struct, dtype=np.float64), (n,))
+        ts = None if seq_tables is None else np.broadcast_to(np.asarray(thr_seq, dtype=np.float64), (n,))
+        pos, mo, sq_l, st_l = [], [], [], []
+        for k in range(n):
+            if seq_tables is None:
+                st = oracle.stream_letters_f64(stream.codes, struct_tables[k])
+                p = oracle.stream_hits(None, st, -np.inf, tt[k])
+                sq = None
+            else:
+                sq = oracle.stream_seq(stream.codes, seq_tables[k])
+                st = oracle.stream_letters_f64(stream.codes2, struct_tables[k])
+                p = oracle.stream_hits(sq, st, ts[k], tt[k])
+            pos.append(p)
+            mo.append(np.full(p.size, k, dtype=np.int32))
+            st_l.append(st[p])
+            sq_l.append(np.zeros(p.size, dtype=np.float32) if sq is None else sq[p])
+        pos, mo, sq_l, st_l = np.concatenate(pos), np.concatenate(mo), np.concatenate(sq_l), np.concatenate(st_l)
+        order = np.lexsort((mo, pos))
+        return pos[order], mo[order], (None if seq_tables is None else sq_l[order]), st_l[order]
+
+
+def test_letter_library_branches_of_the_scanner_equal_the_per_motif_loops(tmp_path):
+    """`-q struct_library structs.fa` and `-p seq_library -q struct_library seqs.fa structs.fa` (SURVEY 8f N1 x N4): with an engine
+    that offers library_hits_letters the scanner makes ONE call per PFM width; the tables are those of the per-motif / per-pair
+    loops (the reference's shape: one motif per side, rnascan.py:262) byte for byte"""
+    rng = np.random.default_rng(77)
+    seq_m, st_m = [], []
+    for k in range(9):
+        w = int(rng.choice([6, 6, 9, 9, 9, 33]))           # 33: too wide for the structure-letter library kernel -> its own scan
+        seq_m.append(("RBP%02d" % k, list("ACGU"), rng.dirichlet(np.full(4, 0.5), size=w)))
+        st_m.append(("RBP%02d" % k, list("EHTBLRM"), rng.dirichlet(np.full(7, 0.5), size=w)))
+    lib_s, lib_t = str(tmp_path / "s.pfm"), str(tmp_path / "t.pfm")
+    _write_multi_pfm(lib_s, seq_m)
+    _write_multi_pfm(lib_t, st_m)
+    with open(tmp_path / "s.fa", "w") as f, open(tmp_path / "t.fa", "w") as g:
+        for i in range(25):
+            L = int(rng.integers(0, 400))
+            f.write(">r%d a\n%s\n" % (i, "".join(rng.choice(list("ACGUN"), size=L, p=[.24, .24, .24, .24, .04]))))
+            g.write(">r%d b\n%s\n" % (i, "".join(rng.choice(list("EHTBLRMehtx"), size=L))))
+    calls = []
+
+    class Counting(_OracleLetterLibraries):
+        def library_hits_letters(self, *a, **k):
+            calls.append(a[2].shape)
+            return _OracleLetterLibraries.library_hits_letters(self, *a, **k)
+
+    for argv in (["-q", lib_t, "-u", "-m", "1", str(tmp_path / "t.fa")],
+                 ["-p", lib_s, "-q", lib_t, "-u", "-m", "-1", str(tmp_path / "s.fa"), str(tmp_path / "t.fa")]):
+        del calls[:]
+        got, want = io.StringIO(), io.StringIO()
+        cli.main(argv, engine=Counting(), out=got)
+        cli.main(argv, engine=OracleEngine(), out=want)
+        assert got.getvalue() == want.getvalue() and want.getvalue().count("\n") > 30
+        assert len(calls) >= 2 and all(len(shape) == 3 and shape[0] > 1 for shape in calls)      # one call per width, several motifs each
