@@ -385,8 +385,14 @@ def main():
     # ---- this rank's memory floor (tools/hbm_mixed on THIS rank's GPU): a slow rank and a badly placed one look different
     rank_floor = None
     if not is_lib and args.mode == "scores" and (seq_only or args.profile_dtype == "float32") and not args.from_host:
-        rank_floor = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned", device=local_rank,
-                                      c2=seq_only)
+        # one rank after the other: the tool is a child process on the rank's GPU, and a node should never see more than ONE extra
+        # process beside the N ranks (process limits of shared boxes), nor two floors disturbing each other's memory traffic
+        for turn in range(world):
+            if turn == rank:
+                rank_floor = live_mixed_floor(args.records, args.length, placed=placed is not None and args.placement == "tuned",
+                                              device=local_rank, c2=seq_only)
+            if dist is not None:
+                dist.barrier()
 
     # ---- per-rank parity sample (multi-GPU runs): a few records of THIS rank's shard against the CPU oracle
     rank_parity = None
