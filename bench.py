@@ -493,7 +493,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": ("k_letters_pre" if args.mode != "scores" else ("k_letters_fixed" if 2 <= args.width <= 16 and not os.environ.get("PFMSCAN_LETTERS_GENERIC") else "k_letters")) if seq_only else (
+                "kernel": ("k_letters_pre" if args.mode != "scores" else ("k_letters_fixed" if 2 <= args.width <= 32 and not os.environ.get("PFMSCAN_LETTERS_GENERIC") else "k_letters")) if seq_only else (
                     "k_profile_fixed" if (args.mode in ("scores", "hits") and 9 <= args.width <= 18 and not os.environ.get("PFMSCAN_PROFILE_GENERIC")) else "k_profile"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(step_ms.min()),
                 "kernel_ms_max": float(step_ms.max()), "algorithmic_bytes_per_launch": alg_bytes,

@@ -104,7 +104,7 @@ bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream,
 // letters-only scans of PFMs wider than PFMSCAN_MAX_M: codes in LDS, the table streamed through LDS in 64-row slabs
 bool launch_wide_letters(const ScanArgs &a, hipStream_t stream, hipError_t *err);
 bool launch_profile_fixed(const ScanArgs &a, hipStream_t stream, hipError_t *err);     // pfmscan_profile_fixed.hip
-bool launch_letters_fixed(const ScanArgs &a, hipStream_t stream, hipError_t *err);     // pfmscan_letters_fixed.hip: all float32 scores, widths 2..16
+bool launch_letters_fixed(const ScanArgs &a, hipStream_t stream, hipError_t *err);     // pfmscan_letters_fixed.hip: all float32 scores, widths 2..32
 hipError_t launch_letters_at(const ScanArgs &a, const int64_t *cand_pos, const float *cand_seq,
                              const unsigned long long *cand_count, int cand_shards, int64_t cand_shard_cap,
                              hipStream_t stream);

@@ -1359,7 +1359,7 @@ static hipError_t launch_letters(const ScanArgs &a, const Tuning &t, hipStream_t
     if (launch_letters_quad(a, t, stream, &e)) return e;     // PFMSCAN_QUAD=1 only: measured slower (profiles/r3/NOTES.md, "tried and dropped")
     if (launch_letters_cred(a, t, stream, &e)) return e;
     if (launch_letters_cred8(a, t, stream, &e)) return e;    // fp64 hits of a generic alphabet at a finite threshold
-    if (launch_letters_fixed(a, stream, &e)) return e;       // all float32 scores, widths 2 .. 16: the width is a compile-time constant
+    if (launch_letters_fixed(a, stream, &e)) return e;       // all float32 scores, widths 2 .. 32: the width is a compile-time constant
     if (a.m <= 16) return launch_letters_ndw<5>(a, t, stream);
     if (a.m <= 32) return launch_letters_ndw<9>(a, t, stream);
     return launch_letters_ndw<17>(a, t, stream);

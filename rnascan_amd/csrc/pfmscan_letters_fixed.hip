@@ -14,7 +14,8 @@
 //   * the width is a constant: exactly M + 3 table offsets are extracted per round (the generic kernel extracts W + 15 and
 //     guards every row), every row offset is an immediate of its ds_read_b64.
 // All code loads of the tile are issued before anything else and parked in LDS (CodeStage), then the rounds only store: no
-// load ever queues behind a store (vmcnt is one in-order queue).  Widths 2 .. 16; others run the generic kernel.
+// load ever queues behind a store (vmcnt is one in-order queue).  Widths 2 .. 32 (the reference's example PFMs are 18 wide); others run the
+// generic kernel.
 #include <cstdlib>
 #include "pfmscan_device.hpp"
 
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(BLOCK) void k_letters_fixed(const ScanArgs a)
     constexpr int LET_TILE = BLOCK * W * ROUNDS;      // 4096 windows per workgroup
     constexpr int NB = M + W - 1;                     // code bytes a lane reads per round
     constexpr int NW = (NB + 3) / 4;                  // ... as dwords (the lane's first window starts on a 4-byte boundary)
-    static_assert(M >= 2 && M <= 16 && NB + 1 <= CODE_HALO, "width outside this kernel's range");
+    static_assert(M >= 2 && M <= 32 && NB + 1 <= CODE_HALO, "width outside this kernel's range");
     __shared__ __align__(16) double pair[64];         // [c0 + 8 c1] = (0.0 + T[0][c0]) + T[1][c1]
     __shared__ __align__(16) double tbl[M * 8];       // rows 2 .. M - 1 are used
     __shared__ __align__(16) uint8_t cbuf[LET_TILE + CODE_HALO];
@@ -100,6 +101,8 @@ bool launch_letters_fixed(const ScanArgs &a, hipStream_t stream, hipError_t *err
 #define FIXED_WIDTH(W) case W: hipLaunchKernelGGL((k_letters_fixed<W>), dim3(grid), dim3(BLOCK), 0, stream, a); break;
     FIXED_WIDTH(2) FIXED_WIDTH(3) FIXED_WIDTH(4) FIXED_WIDTH(5) FIXED_WIDTH(6) FIXED_WIDTH(7) FIXED_WIDTH(8) FIXED_WIDTH(9)
     FIXED_WIDTH(10) FIXED_WIDTH(11) FIXED_WIDTH(12) FIXED_WIDTH(13) FIXED_WIDTH(14) FIXED_WIDTH(15) FIXED_WIDTH(16)
+    FIXED_WIDTH(17) FIXED_WIDTH(18) FIXED_WIDTH(19) FIXED_WIDTH(20) FIXED_WIDTH(21) FIXED_WIDTH(22) FIXED_WIDTH(23) FIXED_WIDTH(24)
+    FIXED_WIDTH(25) FIXED_WIDTH(26) FIXED_WIDTH(27) FIXED_WIDTH(28) FIXED_WIDTH(29) FIXED_WIDTH(30) FIXED_WIDTH(31) FIXED_WIDTH(32)
 #undef FIXED_WIDTH
     default: return false;
     }

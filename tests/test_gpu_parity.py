@@ -663,9 +663,9 @@ def test_placed_arrays_hold_what_is_written_and_scan_like_any_other(ctx, oracle)
     motif.close()
 
 
-@pytest.mark.parametrize("m", list(range(2, 17)))
+@pytest.mark.parametrize("m", list(range(2, 33)))
 def test_fixed_width_letters_kernel_equals_the_generic_one(ctx, oracle, monkeypatch, m):
-    """k_letters_fixed (all float32 scores, widths 2..16: four windows per lane, rows 0 + 1 as one pair look-up built in the
+    """k_letters_fixed (all float32 scores, widths 2..32: four windows per lane, rows 0 + 1 as one pair look-up built in the
     reference's order) gives the width-generic k_letters' bits -- and the oracle's -- on ragged records with foreign letters,
     -inf cells, 8-letter codes and every tail length of the last tile"""
     rng = np.random.default_rng(4000 + m)
