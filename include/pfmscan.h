@@ -385,6 +385,10 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
  * credits uint16 [ceil(m/4)][256], entry index c0 | c1 << 2 | c2 << 4 | c3 << 6 over the letters of motif positions
  * 4t .. 4t+3, 16-bit credits.  A window whose credits sum modulo 2^16 has bit 15 clear cannot be a hit. */
 int pfmscan_debug_quad_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack);
+/* ... and the single-letter credits k_library8 uses for ONE motif of a structure-letter library (pfmscan_library_create_letters
+ * without sequence tables): credits uint16 [4 ceil(m/4)][8] -- the width padded to a multiple of 4 with rows of full credit --
+ * 16-bit sums, bit 15 clear = the window cannot be a hit (matrix.py:25-43 score, strict `>` of rnascan.py:263); m <= 32. */
+int pfmscan_debug_library8_credits(const double *letter_table, int m, double thr, uint16_t *credits, double *slack);
 
 /* The same for the SINGLE-letter credit table of the generic-alphabet hits kernel (k_letters_cred8, PFMs up to width 32,
  * letter_table double [m][8] with up to 7 letters): credits uint16 [m][8], entry index = the letter code; NaN and -inf

@@ -33,7 +33,7 @@ SYMBOLS = [
     "pfmscan_stage", "pfmscan_scan_staged", "pfmscan_hits_staged", "pfmscan_hits_adaptive_dev",
     "pfmscan_library_create", "pfmscan_library_destroy", "pfmscan_library_info", "pfmscan_library_hits_dev",
     "pfmscan_library_hits_staged", "pfmscan_library_hits_host", "pfmscan_library_hits_pipeline_host", "pfmscan_debug_credit_table",
-    "pfmscan_library_create_letters", "pfmscan_library_hits_letters_dev", "pfmscan_library_hits_letters_host",
+    "pfmscan_library_create_letters", "pfmscan_library_hits_letters_dev", "pfmscan_library_hits_letters_host", "pfmscan_debug_library8_credits",
     "pfmscan_debug_quad_table", "pfmscan_debug_credit8_table",
     "pfmscan_hits_pipeline_host", "pfmscan_staged_positions",
     "pfmscan_hits_letters_f64_dev", "pfmscan_hits_letters_f64_staged", "pfmscan_hits_letters_f64_host",
@@ -994,6 +994,23 @@ def quad_table(letter_table, thr_seq):
     rc = L.pfmscan_debug_quad_table(_ptr(T), m, float(thr_seq), _ptr(out), ctypes.byref(slack))
     if rc != OK:
         raise ValueError("pfmscan_debug_quad_table: bad argument")
+    return out, slack.value
+
+
+def library8_credits(letter_table, thr):
+    """Host-only diagnostic: the single-letter credits k_library8 uses for ONE motif of a structure-letter library
+    -> (credits uint16 [4 ceil(m/4)][8], slack in score units; inf: no prefilter for this motif)"""
+    L = load()
+    T = np.ascontiguousarray(letter_table, dtype=np.float64)
+    if T.ndim != 2 or T.shape[1] != NCODE:
+        raise ValueError("letter_table must be [m][8]")
+    rows = (T.shape[0] + 3) // 4 * 4
+    out = np.zeros((rows, 8), dtype=np.uint16)
+    slack = ctypes.c_double(0.0)
+    L.pfmscan_debug_library8_credits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    rc = L.pfmscan_debug_library8_credits(_ptr(T), T.shape[0], float(thr), _ptr(out), ctypes.byref(slack))
+    if rc != OK:
+        raise ValueError("pfmscan_debug_library8_credits: bad argument")
     return out, slack.value
 
 

@@ -396,6 +396,18 @@ int pfmscan_debug_credit_table(const double *letter_table, int m, double thr_seq
     return PFMSCAN_OK;
 }
 
+int pfmscan_debug_library8_credits(const double *letter_table, int m, double thr, uint16_t *credits, double *slack)
+{
+    if (!letter_table || !credits || m < 1 || m > 32 || std::isnan(thr)) return PFMSCAN_E_BADARG;
+    const int rows = lib8_rows(m);                        // the table of a letter library: the width padded to a multiple of 4 with full-credit rows
+    std::vector<double> r8((size_t)rows * 8, 0.0);
+    for (int j = 0; j < m; ++j)
+        for (int c = 0; c < 8; ++c) r8[(size_t)j * 8 + c] = std::isnan(letter_table[j * 8 + c]) ? -INFINITY : letter_table[j * 8 + c];
+    const double s = build_credits(r8.data(), rows, thr, credits, 16, 8);
+    if (slack) *slack = s;
+    return PFMSCAN_OK;
+}
+
 int pfmscan_debug_quad_table(const double *letter_table, int m, double thr_seq, uint16_t *credits, double *slack)
 {
     if (!letter_table || !credits || m < 1 || m > 32 || std::isnan(thr_seq)) return PFMSCAN_E_BADARG;

@@ -215,3 +215,52 @@ def test_single_letter_credits_dense_thresholds_are_flagged():
     assert _lib.credit8_table(T, -50.0)[1] == 2
     assert _lib.credit8_table(T, 4.0)[1] == 1
     assert _lib.credit8_table(T, 1e9)[1] == 1
+
+
+# ---- single-letter credits of the structure-letter LIBRARY kernel (k_library8: rows padded to a multiple of 4) -----------------
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("special", ["none", "neg_inf", "nan", "pos_inf"])
+def test_library8_credits_never_drop_a_hit(m, special):
+    """every window over the 8 codes of width m -- and every code in the positions the PADDING rows look at (a lane's look-ups
+    run over 4 ceil(m/4) positions): a window whose fp64 score exceeds the threshold always has bit 15 of its 16-bit credit sum
+    set, whatever follows it; sums stay inside their 16-bit field; foreign letters inside the window never pass"""
+    rng = np.random.default_rng(91 * m + len(special))
+    rows = (m + 3) // 4 * 4
+    codes = np.array(list(itertools.product(range(8), repeat=m)), dtype=np.int64)
+    for trial in range(4):
+        T = np.full((m, 8), np.nan)
+        T[:, :7] = rng.normal(-0.5, 2.5, size=(m, 7)) * rng.choice([1.0, 1.0, 25.0])
+        r = rng.random((m, 7))
+        if special == "neg_inf":
+            T[:, :7][r < 0.2] = -np.inf
+        elif special == "nan":
+            T[:, :7][r < 0.15] = np.nan
+        elif special == "pos_inf":
+            T[:, :7][r < 0.1] = np.inf
+        s = np.zeros(codes.shape[0])
+        with np.errstate(invalid="ignore"):
+            for j in range(m):
+                s = s + T[j, codes[:, j]]
+        fin = np.sort(s[np.isfinite(s)])
+        thrs = [6.0, 0.0, -3.5, 1e4, -1e4]
+        if fin.size:
+            thrs += [float(fin[int(q * (fin.size - 1))]) for q in (0.0, 0.5, 0.9, 0.99, 1.0)]
+            thrs += [float(np.nextafter(fin[int(0.9 * (fin.size - 1))], -np.inf))]
+        for thr in thrs:
+            credits, slack = _lib.library8_credits(T, thr)
+            assert credits.shape == (rows, 8)
+            if (T[:, :7] == np.inf).any():
+                assert np.isinf(slack) and (credits[0] == 0x8000).all()      # no prefilter: every window goes to the exact pass
+                continue
+            pad = credits[m:]
+            assert (pad == pad[:, :1]).all()                               # a padding row gives every code the same credit ...
+            tot = np.zeros(codes.shape[0], dtype=np.int64)
+            for j in range(m):
+                tot += credits[j, codes[:, j]].astype(np.int64)
+            tot += int(pad[:, 0].astype(np.int64).sum())                   # ... so what follows the window cannot matter
+            assert tot.max() <= 65535
+            flagged = (tot & 0x8000) != 0
+            with np.errstate(invalid="ignore"):
+                hit = s > thr
+            assert not (hit & ~flagged).any(), (m, special, thr)
+            assert not flagged[(codes == 7).any(axis=1)].any()
