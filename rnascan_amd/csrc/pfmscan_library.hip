@@ -36,8 +36,7 @@
 #include <math.h>
 #include <type_traits>
 
-#include "pfmscan_internal.hpp"
-#include "pfmscan_exact.hpp"
+#include "pfmscan_device.hpp"
 
 namespace pfmscan {
 
@@ -251,9 +250,7 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
 {
     int g_next = NG;
     int qs = __builtin_amdgcn_readfirstlane(qn);      // the queue length is wave-uniform: keep it (and the branches on it) scalar
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g >= ng_real) break;                      // wave-uniform: the groups from here on hold no motif
+    auto group = [&](const int g) {
         const u32x4 acc = lib_credits<K, NP>(rowp, g * GS);
         const bool flag = ((acc.x | acc.y | acc.z | acc.w) & (lib_mpg(NP) == 12 ? 0x20080200u : 0x80008000u)) != 0u;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(flag);
@@ -267,6 +264,19 @@ __device__ __forceinline__ int lib_octets_fast(const lds_cptr (&rowp)[NP], int &
             qs = fits ? qs + n : qs;
             asm volatile("" : "+s"(qs), "+s"(g_next));
             if (fits) lib_push<lib_mpg(NP)>(acc, flag, mk, at, g, relpos, cw, q_pos, q_p0, q_p1);
+        }
+    };
+    if constexpr (GS == 128) {
+        // k_library8: hipcc leaves the pragma loop below ROLLED for this kernel (-Wpass-failed; 16 row addresses advanced per
+        // group instead of 16 immediates) -- expanded by template, the groups past ng_real skipped by a scalar branch each
+        static_for<0, NG>([&](auto gc) {
+            if ((int)gc < ng_real) group((int)gc);
+        });
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g >= ng_real) break;                  // wave-uniform: the groups from here on hold no motif
+            group(g);
         }
     }
     qn = qs;
