@@ -206,14 +206,7 @@ int pfmscan_motif_create(pfmscan_ctx *ctx, const double *letter_table, const dou
                 pair_sums(letter_table, m, mo->h_pairsum);
                 mo->has_pairsum = true;
                 mo->h_quadsum = new (std::nothrow) double[(size_t)((m + 3) / 4) * 256];
-                if (mo->h_quadsum) {
-                    quad_sums(letter_table, m, mo->h_quadsum);
-                    if (hipMalloc((void **)&mo->d_quad, 256 * 16) != hipSuccess) {
-                        delete[] mo->h_quadsum;
-                        mo->h_quadsum = nullptr;
-                        mo->d_quad = nullptr;
-                    }
-                }
+                if (mo->h_quadsum) quad_sums(letter_table, m, mo->h_quadsum);
             }
             if (four) e = hipMalloc((void **)&mo->d_pairs, sizeof(float) * pairs.size());
             if (four && e == hipSuccess) e = hipMemcpy(mo->d_pairs, pairs.data(), sizeof(float) * pairs.size(), hipMemcpyHostToDevice);
@@ -243,7 +236,7 @@ void pfmscan_motif_destroy(pfmscan_motif *mo)
     if (mo->d_letters) (void)hipFree(mo->d_letters);
     if (mo->d_pairs) (void)hipFree(mo->d_pairs);
     if (mo->d_struct) (void)hipFree(mo->d_struct);
-    if (mo->d_quad) (void)hipFree(mo->d_quad);
+    quad_cache_release(mo->quad_cache);
     delete[] mo->h_quadsum;
     delete[] mo->h_letters;
     delete mo;
@@ -275,8 +268,8 @@ int pfmscan::check_and_fill(pfmscan_ctx *ctx, const pfmscan_motif *mo, const uin
     a.pair_eps = mo->pair_eps;
     a.h_pairsum = mo->has_pairsum ? mo->h_pairsum : nullptr;
     a.h_quadsum = mo->h_quadsum;
-    a.d_quad = mo->d_quad;
-    a.quad_thr = &mo->quad_thr;
+    a.d_quad = nullptr;
+    a.quad_cache = &mo->quad_cache;
     a.cred_cache = &mo->cred_cache;
     a.h_letters = mo->h_letters;
     a.cred8_cache = &mo->cred8_cache;

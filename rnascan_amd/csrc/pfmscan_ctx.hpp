@@ -15,8 +15,7 @@ struct pfmscan_motif {
     double h_pairsum[16 * 16];     // exact two-letter sums (m <= 32, 4-letter alphabets): operand of the integer prefilter
     bool has_pairsum = false;
     double *h_quadsum = nullptr;   // exact four-letter sums [ceil(m/4)][256] (same motifs): operand of k_letters_quad's credits
-    uint32_t *d_quad = nullptr;    // device: the credit table of the threshold quad_thr (rebuilt when the threshold changes)
-    mutable double quad_thr = __builtin_nan("");
+    mutable pfmscan::QuadCache quad_cache;   // k_letters_quad's credit tables by threshold (device + pinned host, allocated at first use)
     mutable pfmscan::CredCache cred_cache;
     double *h_letters = nullptr;   // host copy of the letter table [m][8] (m <= 32): operand of k_letters_cred8's credits
     mutable pfmscan::Cred8Cache cred8_cache;

@@ -23,6 +23,26 @@ struct Cred8Cache {
     uint16_t cr[32 * 8];
 };
 
+// k_letters_quad's credit tables (launch_letters_quad): a small ring of (threshold, device table) slots kept with the motif.
+// A new threshold goes through the slot's PINNED host copy with hipMemcpyAsync on the caller's stream -- no device-wide
+// synchronisation and no blocking copy inside the asynchronous `_dev` entry points; `ready` orders other streams behind
+// the copy, `used` (recorded after the last launch that read the slot) is what a reuse of the slot waits for.
+struct QuadSlot {
+    double thr = __builtin_nan("");
+    uint32_t *d_tab = nullptr;   // device: 256 entries of up to 16 bytes
+    uint32_t *h_tab = nullptr;   // pinned host copy the asynchronous upload reads
+    hipEvent_t ready = nullptr, used = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool many_streams = false;   // launches from more than one stream have read this slot since it was filled
+};
+struct QuadCache {
+    static constexpr int SLOTS = 4;
+    QuadSlot slot[SLOTS];
+    int next = 0;
+    bool unusable = false;       // the motif's four-letter sums hold +inf / NaN: the fp32 prefilter handles it
+};
+void quad_cache_release(QuadCache &qc);      // pfmscan_kernels.hip: frees the slots' memory and events
+
 struct ScanArgs {
     const uint8_t *codes;        // [n_pos] device, may be null when the motif has no letter table
     const void *profile;         // [n_pos][7] float or double, device, may be null
@@ -37,8 +57,8 @@ struct ScanArgs {
     const double *h_pairsum;     // HOST: [(m+1)/2][16] exact two-letter sums (4-letter alphabets): the launcher builds the
                                  // integer credit table of k_letters_cred from them for the call's threshold
     const double *h_quadsum;     // HOST: [(m+3)/4][256] exact four-letter sums (m <= 32): operand of k_letters_quad's credit table
-    uint32_t *d_quad;            // DEVICE: room for that table (256 entries of up to 16 bytes), owned by the motif
-    double *quad_thr;            // HOST: the threshold d_quad currently holds credits for (NaN: none), owned by the motif
+    const uint32_t *d_quad;      // DEVICE: the table of the call's threshold (a slot of quad_cache; set by the launcher)
+    QuadCache *quad_cache;       // HOST: owned by the motif
     CredCache *cred_cache;       // HOST: owned by the motif
     const uint8_t *codes2;       // two-FASTA combined scan fused into k_letters_cred: the second code stream (device) or null
     const double *letter_table2; // ... and its letter table [m][8] (device); hits then need seq > thr_seq AND letters2 > thr_struct

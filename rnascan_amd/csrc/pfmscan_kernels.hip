@@ -54,6 +54,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <mutex>
 #include "pfmscan_device.hpp"
 #include "pfmscan_profile.hpp"
 
@@ -1280,31 +1281,78 @@ bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream,
     return true;
 }
 
-// four-letter credit tables (k_letters_quad): the table of the call's threshold is built on the host and kept on the
-// device with the motif; it is rebuilt only when the threshold changes
+// four-letter credit tables (k_letters_quad): the table of the call's threshold is built on the host and kept with the motif in
+// a ring of QuadCache::SLOTS (threshold, device table) slots.  A threshold the ring does not hold takes the oldest slot: its
+// table goes through the slot's pinned host copy with hipMemcpyAsync on the CALLER's stream -- the `_dev` entry points stay
+// asynchronous (no hipDeviceSynchronize, no blocking copy: ADVICE round 4 on the cred8 twin of this code).  Ordering:
+// `ready` (recorded behind the copy) is what launches from other streams wait for; `used` (recorded behind every launch that
+// reads the slot) is what the host waits for before it overwrites the slot -- with a device-wide wait only in the case that
+// launches from several streams have read it, whose completion one event cannot vouch for.
+static std::mutex quad_mu;
+
+void quad_cache_release(QuadCache &qc)
+{
+    for (QuadSlot &s : qc.slot) {
+        if (s.used) (void)hipEventSynchronize(s.used);
+        if (s.d_tab) (void)hipFree(s.d_tab);
+        if (s.h_tab) (void)hipHostFree(s.h_tab);
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.used) (void)hipEventDestroy(s.used);
+        s = QuadSlot();
+    }
+}
+
 static bool launch_letters_quad(const ScanArgs &a, const Tuning &t, hipStream_t stream, hipError_t *err)
 {
-    if (!(a.hits && !a.f64_hits && a.pair_table && a.h_quadsum && a.d_quad && a.quad_thr && a.m <= 32 && t.credits && t.quad && std::isfinite(a.thr_seq)))
+    if (!(a.hits && !a.f64_hits && a.pair_table && a.h_quadsum && a.quad_cache && a.m <= 32 && t.credits && t.quad && std::isfinite(a.thr_seq)))
         return false;
     constexpr int QUAD_TILE = BLOCK * 16;
-    const int nq = (a.m + 3) / 4, nd = (nq + 1) / 2;
+    constexpr size_t TAB_BYTES = 256 * 16;
+    const int nq = (a.m + 3) / 4;
     const int edw = nq <= 2 ? 1 : (nq <= 4 ? 2 : 4);       // dwords per table entry
-    if (!(*a.quad_thr == a.thr_seq)) {
+    QuadCache &qc = *a.quad_cache;
+    std::lock_guard<std::mutex> lock(quad_mu);
+    if (qc.unusable) return false;
+    QuadSlot *slot = nullptr;
+    for (QuadSlot &s : qc.slot)
+        if (s.d_tab && s.h_tab && s.ready && s.used && s.thr == a.thr_seq) slot = &s;
+    if (!slot) {
         std::vector<uint16_t> cr((size_t)nq * 256);
         const double slack = build_credits(a.h_quadsum, nq, a.thr_seq, cr.data(), 16, 256);
-        if (!std::isfinite(slack)) return false;           // +inf / NaN four-letter sums: the fp32 prefilter handles those
-        std::vector<uint32_t> tab((size_t)256 * edw, 0u);
+        if (!std::isfinite(slack)) {                       // +inf / NaN four-letter sums: the fp32 prefilter handles those
+            qc.unusable = true;                            // (a property of the motif, not of the threshold)
+            return false;
+        }
+        slot = &qc.slot[qc.next];
+        qc.next = (qc.next + 1) % QuadCache::SLOTS;
+        if (!slot->d_tab || !slot->h_tab || !slot->ready || !slot->used) {     // first use (or an allocation failed half way)
+            slot->thr = __builtin_nan("");
+            if (!slot->d_tab && (*err = hipMalloc((void **)&slot->d_tab, TAB_BYTES)) != hipSuccess) return true;
+            if (!slot->h_tab && (*err = hipHostMalloc((void **)&slot->h_tab, TAB_BYTES, hipHostMallocDefault)) != hipSuccess) return true;
+            if (!slot->ready && (*err = hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming)) != hipSuccess) return true;
+            if (!slot->used && (*err = hipEventCreateWithFlags(&slot->used, hipEventDisableTiming)) != hipSuccess) return true;
+        } else {
+            // the launches that read the old table (and the copy that filled it) must be over before the pinned copy changes
+            *err = slot->many_streams ? hipDeviceSynchronize() : hipEventSynchronize(slot->used);
+            if (*err != hipSuccess) return true;
+        }
+        slot->thr = __builtin_nan("");
+        std::memset(slot->h_tab, 0, TAB_BYTES);
         for (int i = 0; i < 256; ++i)
-            for (int r = 0; r < nq; ++r) tab[(size_t)i * edw + (r >> 1)] |= (uint32_t)cr[(size_t)r * 256 + i] << (16 * (r & 1));
-        (void)nd;
-        // another launch (on any stream) may still read the old table: threshold changes are rare, wait for the device
-        *err = hipDeviceSynchronize();
-        if (*err != hipSuccess) return true;
-        *err = hipMemcpy(a.d_quad, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
-        if (*err != hipSuccess) return true;
-        *a.quad_thr = a.thr_seq;
+            for (int r = 0; r < nq; ++r) slot->h_tab[(size_t)i * edw + (r >> 1)] |= (uint32_t)cr[(size_t)r * 256 + i] << (16 * (r & 1));
+        if ((*err = hipMemcpyAsync(slot->d_tab, slot->h_tab, (size_t)256 * edw * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return true;
+        if ((*err = hipEventRecord(slot->ready, stream)) != hipSuccess) return true;
+        if ((*err = hipEventRecord(slot->used, stream)) != hipSuccess) return true;     // (a reuse before any launch waits for the copy)
+        slot->thr = a.thr_seq;
+        slot->last_stream = stream;
+        slot->many_streams = false;
+    } else if (slot->last_stream != stream) {
+        if ((*err = hipStreamWaitEvent(stream, slot->ready, 0)) != hipSuccess) return true;   // the copy ran on another stream
+        slot->many_streams = true;
+        slot->last_stream = stream;
     }
     ScanArgs b = a;
+    b.d_quad = slot->d_tab;
     const int64_t ntiles = (a.n_pos + QUAD_TILE - 1) / QUAD_TILE;
     b.tiles_per_block = walk_tiles(ntiles, t);
     if (t.tiles_per_block > 0) b.tiles_per_block = t.tiles_per_block;
@@ -1320,6 +1368,7 @@ static bool launch_letters_quad(const ScanArgs &a, const Tuning &t, hipStream_t 
     default: hipLaunchKernelGGL((k_letters_quad<8>), dim3(g), dim3(BLOCK), 0, stream, b); break;
     }
     *err = hipGetLastError();
+    if (*err == hipSuccess) *err = hipEventRecord(slot->used, stream);
     return true;
 }
 

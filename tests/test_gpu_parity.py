@@ -688,3 +688,48 @@ def test_fixed_width_letters_kernel_equals_the_generic_one(ctx, oracle, monkeypa
         assert_f32_bits_equal(got[keep], want[keep])
         assert np.array_equal(got.view(np.uint32)[~np.isnan(got)], gen.view(np.uint32)[~np.isnan(gen)]) and np.array_equal(np.isnan(got), np.isnan(gen))
     motif.close()
+
+
+def test_quad_tables_by_threshold_across_streams(oracle, monkeypatch):
+    """k_letters_quad (PFMSCAN_QUAD=1: the four-letter credit tables, an A/B path) keeps its credit tables per threshold in a ring of four slots, uploaded asynchronously on the caller's
+    stream (no device-wide wait in the `_dev` entry point): seven thresholds cycled through two streams -- slot reuse,
+    a slot filled on one stream and read from the other -- give the oracle's hits every time"""
+    import torch
+    from rnascan_amd import _lib
+    monkeypatch.setenv("PFMSCAN_QUAD", "1")
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(2024)
+    m = 8
+    s = rand_stream(rng, 300, 500, 3000)
+    T = rand_table(rng, m)
+    motif = ctx.motif(letter_table=T)
+    want_seq = oracle.stream_seq(s.codes, T)
+    fin = want_seq[np.isfinite(want_seq)].astype(np.float64)
+    thrs = [float(np.quantile(fin, q)) for q in (0.999, 0.99, 0.995, 0.9995, 0.98, 0.997, 0.9999)]
+    dev = torch.device("cuda", 0)
+    d_codes = torch.from_numpy(s.codes).to(dev)
+    n = int(s.codes.size)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    cap = 1 << 18
+    runs = []
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, thr in enumerate(thrs + thrs[:2]):                 # 9 calls per round: the ring of four turns over twice
+            st = streams[(k + rep) % 2]
+            hp = torch.empty(cap, dtype=torch.int64, device=dev)
+            hs = torch.empty(cap, dtype=torch.float32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            st.wait_stream(torch.cuda.current_stream())
+            ctx.hits_dev(motif, d_codes.data_ptr(), None, _lib.PROFILE_NONE, n, thr, -np.inf, cap, hp.data_ptr(), hs.data_ptr(), None,
+                         cnt.data_ptr(), stream=st.cuda_stream)
+            runs.append((thr, hp, hs, cnt))
+    torch.cuda.synchronize()
+    for thr, hp, hs, cnt in runs:
+        k = int(cnt.item())
+        pos, sc = hp[:k].cpu().numpy(), hs[:k].cpu().numpy()
+        order = np.argsort(pos, kind="stable")
+        want_pos = oracle.stream_hits(want_seq, None, thr, -np.inf)
+        assert np.array_equal(pos[order], want_pos), (thr, k, want_pos.size)
+        assert_f32_bits_equal(sc[order], want_seq[want_pos])
+    motif.close()
+    ctx.close()
