@@ -1225,6 +1225,12 @@ bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream,
     constexpr int CRED_TILE = BLOCK * 16;              // k_letters_cred: 16 windows per lane
     const int npair = (a.m + 1) / 2, nj = (npair + 1) / 2;
     CredCache local, *cc = a.cred_cache ? a.cred_cache : &local;
+    CredTable ct;
+    {
+    // the motif keeps what the last threshold gave; host threads that scan with one motif take turns here and every launch
+    // carries its own copy of the table (as in launch_letters_cred8)
+    static std::mutex cred_mu;
+    std::lock_guard<std::mutex> lock(cred_mu);
     if (!(cc->thr == a.thr_seq) || cc->mode == 0) {
         cc->thr = a.thr_seq;
         const double slack = build_credits(a.h_pairsum, npair, a.thr_seq, cc->cr);
@@ -1259,10 +1265,10 @@ bool launch_letters_cred(const ScanArgs &a, const Tuning &t, hipStream_t stream,
     }
     if (cc->mode != 1) return false;                       // -> k_letters_pre (launch_letters_ndw)
     const uint16_t *cr = cc->cr;
-    CredTable ct;
     std::memset(&ct, 0, sizeof(ct));
     for (int i = 0; i < 16; ++i)
         for (int tr = 0; tr < npair; ++tr) ct.d[i][tr >> 1] |= (uint32_t)cr[tr * 16 + i] << (16 * (tr & 1));
+    }
     ScanArgs b = a;
     const int64_t ntiles = (a.n_pos + CRED_TILE - 1) / CRED_TILE;
     b.tiles_per_block = walk_tiles(ntiles, t);
