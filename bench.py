@@ -460,7 +460,8 @@ def main():
             wl = "C2: %d synthetic RNA records x %d nt per GPU, sequence PFM width %d, uint8 codes" % (args.records, args.length, args.width)
         else:
             wl = ("%s: %d synthetic RNA records x %d nt per GPU, seq PFM + averaged-structure PFM width %d, uint8 codes + %s "
-                  "[n][7] profile, %s" % ("C4 (1M records x 3 kb over 8 GPUs)" if shard.startswith("C4") else "C3", args.records,
+                  "[n][7] profile, %s" % ("C4 (1M records x 3 kb over 8 GPUs)" if shard.startswith("C4") else
+                                          ("C4 (1M records x 3 kb), all of it resident on each GPU" if args.records == 1000000 else "C3"), args.records,
                                           args.length, args.width, args.profile_dtype,
                                           "all-scores (f32 seq + f64 struct per window)" if args.mode == "scores" else "thresholded hits"))
         result = {
