@@ -390,6 +390,74 @@ def test_fullsize_c4_shard_of_125k_records(oracle):
     ctx.close()
 
 
+def test_fullsize_c4_whole_on_one_gpu(oracle):
+    """ALL of BASELINE configs[3] -- 1M records x 3 kb = 3.0x10^9 positions (past 2^31), 87 GB of codes + profile in, 36 GB of
+    scores out -- resident on ONE MI355X and scanned by single launches: deterministic, NaN pattern, fused hits == thresholded
+    scores at 64-bit positions, 48 sampled records (half of them past position 2^31) against the oracle"""
+    import torch
+    import bench
+    from rnascan_amd import _lib
+    if torch.cuda.mem_get_info()[0] < 200e9:
+        pytest.skip("needs 200 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    R4 = 1000000
+    ctx = _lib.Context(0)
+    table, spssm = bench.make_pssms(M)
+    codes, profile, n_pos = bench.make_stream(torch, dev, R4, L, 20240601)
+    torch.cuda.synchronize()
+    assert n_pos > (1 << 31)
+    motif = ctx.motif(table, spssm)
+
+    def scan():
+        a = torch.empty(n_pos, dtype=torch.float32, device=dev)
+        b = torch.empty(n_pos, dtype=torch.float64, device=dev)
+        ctx.scan_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, a.data_ptr(), b.data_ptr())
+        ctx.synchronize()
+        return a, b
+
+    s1, t1 = scan()
+    s1b, t1b = scan()
+    assert torch.equal(s1.view(torch.int32), s1b.view(torch.int32)) and torch.equal(t1.view(torch.int64), t1b.view(torch.int64))
+    del s1b, t1b
+    torch.cuda.empty_cache()
+    assert sum(int(torch.isnan(s1[lo:lo + (1 << 30)]).sum()) for lo in range(0, n_pos, 1 << 30)) == R4 * M
+    thr_s, thr_t = 6.0, -8.0
+    step = 1 << 30                                                   # (torch.nonzero does not take 2^31 elements at once)
+    want = torch.cat([torch.nonzero((s1[lo:lo + step].double() > thr_s) & (t1[lo:lo + step] > thr_t)).flatten() + lo
+                      for lo in range(0, n_pos, step)])
+    cap = int(want.numel()) + 16
+    hp = torch.empty(cap, dtype=torch.int64, device=dev)
+    hs = torch.empty(cap, dtype=torch.float32, device=dev)
+    ht = torch.empty(cap, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.hits_adaptive_dev(motif, codes.data_ptr(), profile.data_ptr(), _lib.PROFILE_F32, n_pos, thr_s, thr_t, cap,
+                          hp.data_ptr(), hs.data_ptr(), ht.data_ptr(), cnt.data_ptr())
+    ctx.synchronize()
+    k = int(cnt.item())
+    assert k == int(want.numel()) and k > 1000
+    order = torch.argsort(hp[:k])
+    assert torch.equal(hp[:k][order], want) and torch.equal(hs[:k][order], s1[want])
+    assert float((ht[:k][order] - t1[want]).abs().max()) <= 1e-6
+    assert int(want.max()) > (1 << 31)
+    rng = np.random.default_rng(44)
+    stride = L + 1
+    first_past = ((1 << 31) + stride - 1) // stride
+    picks = np.concatenate([rng.choice(first_past, size=24, replace=False), first_past + rng.choice(R4 - first_past, size=24, replace=False)])
+    for r in picks:
+        lo = int(r) * stride
+        c = codes[lo:lo + stride].cpu().numpy()
+        p = profile[lo:lo + stride].cpu().numpy()
+        ref_sq, ref_st = oracle.stream_seq(c, table), oracle.stream_struct(p, spssm)
+        got_sq, got_st = s1[lo:lo + L - M + 1].cpu().numpy(), t1[lo:lo + L - M + 1].cpu().numpy()
+        assert np.array_equal(got_sq.view(np.uint32), ref_sq[: L - M + 1].view(np.uint32))
+        assert np.abs(got_st - ref_st[: L - M + 1]).max() <= 1e-6
+    motif.close()
+    ctx.close()
+    del s1, t1, codes, profile, hp, hs, ht, want
+    torch.cuda.empty_cache()
+
+
 def test_fullsize_structure_letter_strings_and_two_fasta(big, oracle):
     """SURVEY 8f N4 at full size (100k x 3 kb structure strings, 7 letters, w = 12): the fp64 letter hits are exactly the
     windows the all-scores output (k_letters<..., double>) says exceed the threshold, with the same bits; doubling the
